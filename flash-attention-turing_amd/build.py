@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""In-tree build of the MI355X attention library and its PyTorch host module.
+
+Replaces the reference's CUDA `setup.py` (reference setup.py:20-49: CUDAExtension with nvcc
+-arch=sm_75).  Two artefacts, both written next to the sources so they travel with the tree:
+
+  csrc/libflash_attn_gfx950.so       HIP kernels + C ABI (include/flash_attn_gfx950.h),
+                                     built with `hipcc --offload-arch=gfx950`; no torch dependency.
+  flash_attn_turing/_C.so            host module (pybind11 + torch C++ API, plain g++ — no HIP
+                                     sources, so torch's hipify pass is never involved); it
+                                     links against the library above and exports
+                                     fwd / bwd / varlen_fwd / varlen_bwd exactly like
+                                     reference csrc/flash_attn/flash_api.cpp:471-476.
+
+hipcc cross-compiles for gfx950 without a GPU.  Usage: `python build.py [--force] [--no-torch]`.
+"""
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+import sysconfig
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+PKG = os.path.join(HERE, "flash_attn_turing")
+INCLUDE = os.path.join(ROOT, "include")
+
+LIB_NAME = "libflash_attn_gfx950.so"
+LIB_PATH = os.path.join(CSRC, LIB_NAME)
+EXT_PATH = os.path.join(PKG, "_C.so")
+
+HIP_SOURCES = ["fa_fwd.hip", "fa_bwd.hip", "fa_capi.hip"]
+HIP_HEADERS = ["fa_device.hpp", "fa_params.hpp", os.path.join(INCLUDE, "flash_attn_gfx950.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-DNDEBUG", "-Wall", "-Wno-unused-function"]
+
+
+def _run(cmd, **kw):
+    print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, **kw)
+
+
+def _digest(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, stamp_value):
+    stamp = target + ".stamp"
+    if not os.path.exists(target) or not os.path.exists(stamp):
+        return True
+    with open(stamp) as f:
+        return f.read().strip() != stamp_value
+
+
+def _write_stamp(target, stamp_value):
+    with open(target + ".stamp", "w") as f:
+        f.write(stamp_value)
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build_kernels(force=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    stamp = _digest(srcs + hdrs, " ".join(HIPCC_FLAGS))
+    if not force and not _stale(LIB_PATH, stamp):
+        print(f"[build] {LIB_NAME} up to date")
+        return LIB_PATH
+    t0 = time.time()
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-I", CSRC, "-I", INCLUDE, "-c", s, "-o", o]
+        print("[build]", " ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    _write_stamp(LIB_PATH, stamp)
+    print(f"[build] {LIB_NAME} built in {time.time() - t0:.1f}s")
+    return LIB_PATH
+
+
+def build_torch_module(force=False):
+    import torch  # noqa: F401  (needed for include/library paths)
+    from torch.utils import cpp_extension as ce
+
+    src = os.path.join(CSRC, "flash_api.cpp")
+    stamp = _digest([src, os.path.join(INCLUDE, "flash_attn_gfx950.h")], torch.__version__)
+    if not force and not _stale(EXT_PATH, stamp):
+        print("[build] flash_attn_turing/_C.so up to date")
+        return EXT_PATH
+    t0 = time.time()
+    tlib = ce.library_paths()[0]
+    rocm = os.environ.get("ROCM_HOME", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-DTORCH_EXTENSION_NAME=_C", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    for inc in ce.include_paths():
+        cmd += ["-isystem", inc]
+    cmd += ["-isystem", os.path.join(rocm, "include"), "-I", INCLUDE, "-I", sysconfig.get_paths()["include"]]
+    cmd += [src, "-o", EXT_PATH,
+            "-L", tlib, "-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
+            "-L", CSRC, "-l:" + LIB_NAME,
+            "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+            "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    _run(cmd)
+    _write_stamp(EXT_PATH, stamp)
+    print(f"[build] flash_attn_turing/_C.so built in {time.time() - t0:.1f}s")
+    return EXT_PATH
+
+
+def build_all(force=False, torch_module=True):
+    build_kernels(force)
+    if torch_module:
+        build_torch_module(force)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--no-torch", action="store_true", help="only build the C-ABI kernel library")
+    a = ap.parse_args()
+    build_all(a.force, not a.no_torch)
+    sys.exit(0)

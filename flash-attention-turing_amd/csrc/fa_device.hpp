@@ -1,0 +1,195 @@
+// fa_device.hpp — CDNA4 (gfx950) device-side building blocks shared by the forward and
+// backward attention kernels.  Everything here is written for wave64 + MFMA 32x32x16 and the
+// 160 KiB LDS of MI355X; there is no other target.
+//
+// Fragment conventions used throughout (v_mfma_f32_32x32x16_{f16,bf16}, D = A*B + C):
+//   A (32 x 16): lane l holds row  i = l & 31, k = 8*(l >> 5) + j, j = 0..7   (8 x 16-bit = 4 VGPRs)
+//   B (16 x 32): lane l holds col  n = l & 31, k = 8*(l >> 5) + j
+//   C/D (32x32): lane l holds col  n = l & 31, row(r) = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15
+// The contraction index k may be permuted freely as long as A and B use the same
+// permutation; the kernels exploit that to feed a C-layout accumulator straight back in as a
+// B operand (see "k-slot" helpers below) with no LDS round trip and no cross-lane moves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define FA_DEV __device__ __forceinline__
+#define FA_LDS __attribute__((address_space(3)))
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+// Running-max initialiser: finite, so (m_old - m_new) never produces inf - inf = NaN for rows
+// that have not seen a visible key yet (SURVEY.md Appendix A dead-row convention).
+constexpr float kNegBig = -1.0e30f;
+
+struct Strides {
+    int64_t batch, row, head;
+};
+
+// ---- low-precision element traits ----------------------------------------------------------
+template <typename T>
+struct LP;
+
+template <>
+struct LP<_Float16> {
+    static FA_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    // round-to-nearest-even pack (v_cvt_pk_f16_f32): the reference rounds P/dS/O with
+    // cutlass NumericArrayConverter (utils.h:19-27), which is RN as well.
+    static FA_DEV uint32_t pack2(float lo, float hi) {
+        f32x2 x = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
+    }
+    static FA_DEV float to_float(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+};
+
+template <>
+struct LP<__bf16> {
+    static FA_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static FA_DEV uint32_t pack2(float lo, float hi) {
+        f32x2 x = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));  // v_cvt_pk_bf16_f32 (RN)
+    }
+    static FA_DEV float to_float(uint16_t bits) { return __builtin_bit_cast(float, (uint32_t)bits << 16); }
+};
+
+// ---- buffer (SRD) addressing -----------------------------------------------------------------
+// All global traffic of the tiled kernels goes through raw buffer loads/stores: 32-bit per-lane
+// byte offsets against a wave-uniform 64-bit base, and hardware range checking gives the
+// reference's predicated copies (utils.h:49-88: zero-fill on read, drop on write) for free.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+FA_DEV rsrc_t make_rsrc(const void* base, uint32_t num_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ (short)0, (int)num_bytes, 0x00020000);
+}
+FA_DEV u32x4 buf_load16(rsrc_t r, uint32_t byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0); }
+FA_DEV void buf_store16(rsrc_t r, uint32_t byte_off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0); }
+
+// Make a 64-bit pointer provably wave-uniform for the compiler so the descriptor lives in
+// SGPRs and no waterfall loop is generated around each buffer op.
+template <typename P>
+FA_DEV P* uniform_ptr(P* p) {
+    uint64_t v = (uint64_t)p;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (P*)(((uint64_t)hi << 32) | lo);
+}
+
+// ---- LDS tile layout -------------------------------------------------------------------------
+// A staged tile is [rows][D] 16-bit elements, row-major, D*2 bytes per row, with the 16-byte
+// slot index XOR-swizzled per row so that BOTH access patterns used by the kernels are bank
+// conflict free (banks: (addr/4) % 64 for ds_read_b128 / ds_read_b64_tr_b16):
+//   (1) ds_read_b128 "row reads" (MFMA A/B fragments whose 8 k-values are contiguous in the
+//       row): a 16-lane service group touches 16 rows distinct mod 16 at one slot index;
+//   (2) ds_read_b64_tr_b16 "transposed reads" (fragments whose 8 k-values run DOWN a column):
+//       a 32-lane half touches 4 consecutive rows x 64 contiguous bytes.
+// swz(row) = ((row & 3) << 2) | ((row >> 2) & 3) is a bijection on row & 15 (fixes 1) whose
+// top two bits differ across any 4 consecutive rows aligned to 4 (fixes 2: each of the 4 rows
+// lands in a different 64-byte bank quarter).  For D = 64 (128-byte rows, two rows per 256-byte
+// bank row) the row parity supplies the missing bit.
+template <int D>
+FA_DEV uint32_t lds_tile_off(uint32_t row, uint32_t slot /* 16-byte slot in row, 0..D/8-1 */) {
+    if constexpr (D == 128) {
+        uint32_t s = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        return row * 256u + (s << 4);
+    } else {
+        static_assert(D == 64, "head_dim must be 64 or 128");
+        // 8 slots per row. bits: slot = (c1 c0 | w) with chunk pairs; use row bits 1..3.
+        uint32_t s = slot ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+        return row * 128u + (s << 4);
+    }
+}
+
+FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }
+FA_DEV void lds_write16(FA_LDS char* base, uint32_t off, u32x4 v) { *(FA_LDS u32x4*)(base + off) = v; }
+FA_DEV void lds_write8(FA_LDS char* base, uint32_t off, u32x2 v) { *(FA_LDS u32x2*)(base + off) = v; }
+
+// Hardware transposed read (ds_read_b64_tr_b16). Within each 16-lane group, lane L supplies the
+// address of 4 consecutive 16-bit elements; lane L receives, for j = 0..3, element (L & 3) of
+// the 8 bytes addressed by lane 4*j + (L >> 2).  With lane L pointing at row (L >> 2), columns
+// 4*(L & 3).. of a 4 x 16 block, lane L therefore gets column L of that block, rows 0..3.
+FA_DEV u32x2 lds_read_tr8(const FA_LDS char* base, uint32_t off) {
+    i16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS i16x4v*)(base + off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+// ---- cross-lane helpers ----------------------------------------------------------------------
+// value held by lane ^ 32 (the other half-wave owns the other 16 rows of a 32x32 C tile column)
+FA_DEV float other_half(float x) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // r[0]: lanes 0-31 keep own, lanes 32-63 receive lanes 0-31; r[1]: lanes 0-31 receive 32-63, 32-63 keep own
+    uint32_t o = (threadIdx.x & 32) ? r[0] : r[1];
+    return __builtin_bit_cast(float, o);
+}
+FA_DEV float max_both_halves(float x) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+FA_DEV float sum_both_halves(float x) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+
+FA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+FA_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+FA_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Row index (0..31) inside a 32x32 C tile owned by accumulator register r of this lane.
+FA_DEV int c_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Pack accumulator registers [8*half .. 8*half+7] of a C tile to 8 low-precision values =
+// one MFMA B (or A) fragment whose k-slots are, for this lane (hi = lane >> 5):
+//     k-slot j  <->  tile row 16*half + 4*hi + {0,1,2,3,8,9,10,11}[j]
+// The matching A operand must be read with the same row set (see tr-read address helpers).
+template <typename T>
+FA_DEV u32x4 pack_c_half(const f32x16& c, int half) {
+    u32x4 o;
+    if (half == 0) {
+        o.x = LP<T>::pack2(c[0], c[1]);
+        o.y = LP<T>::pack2(c[2], c[3]);
+        o.z = LP<T>::pack2(c[4], c[5]);
+        o.w = LP<T>::pack2(c[6], c[7]);
+    } else {
+        o.x = LP<T>::pack2(c[8], c[9]);
+        o.y = LP<T>::pack2(c[10], c[11]);
+        o.z = LP<T>::pack2(c[12], c[13]);
+        o.w = LP<T>::pack2(c[14], c[15]);
+    }
+    return o;
+}
+
+// XCD-aware work-item decode.  Blocks are dispatched round-robin over the 8 XCDs
+// (block id % 8); every XCD has a private 4 MiB L2.  All tiles that share one (batch, head)
+// K/V stream are placed on the same XCD so K/V is fetched from HBM once per XCD, not once per
+// workgroup.  Falls back to the plain order when batch*heads is not a multiple of 8.
+FA_DEV void decode_block(uint32_t id, uint32_t tiles_per_bh, uint32_t n_bh, uint32_t& tile, uint32_t& bh) {
+    if ((n_bh & 7u) == 0) {
+        uint32_t xcd = id & 7u, slot = id >> 3;
+        bh = (slot / tiles_per_bh) * 8u + xcd;
+        tile = slot % tiles_per_bh;
+    } else {
+        bh = id / tiles_per_bh;
+        tile = id % tiles_per_bh;
+    }
+}
+
+}  // namespace fa

@@ -1,0 +1,59 @@
+// fa_params.hpp — kernel-side parameter blocks (passed by value in the kernarg segment).
+// Counterpart of the reference's Flash_fwd_params / Flash_bwd_params (src/flash.h:6-76), with
+// real element strides and 64-bit offsets (the reference's int32 offsets in block_info.h:15-21
+// overflow at b=32, s=16k, h=32, d=128 = 2^31 elements).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+struct TStride {
+    int64_t batch, row, head;   // in elements
+};
+
+struct FwdKernelParams {
+    const void* q_ptr;
+    const void* k_ptr;
+    const void* v_ptr;
+    void* o_ptr;
+    float* lse_ptr;
+    const int32_t* cu_seqlens_q;
+    const int32_t* cu_seqlens_k;
+    TStride q, k, v, o;
+    int64_t lse_row_stride;     // elements between consecutive (batch, head) rows of lse
+    int32_t b, seqlen_q, seqlen_k, h, h_k, h_ratio, d;
+    int32_t is_causal;
+    uint32_t n_q_tiles;         // filled by the launcher
+    float scale_log2e;          // log2(e) / sqrt(d)
+    float scale;                // 1 / sqrt(d)
+};
+
+struct BwdKernelParams {
+    const void* q_ptr;
+    const void* k_ptr;
+    const void* v_ptr;
+    const void* o_ptr;
+    const void* do_ptr;
+    const float* lse_ptr;
+    float* dsum_ptr;            // D = rowsum(dO * O), layout of lse
+    void* dq_ptr;
+    void* dk_ptr;
+    void* dv_ptr;
+    const int32_t* cu_seqlens_q;
+    const int32_t* cu_seqlens_k;
+    TStride q, k, v, o, dout, dq, dk, dv;
+    int64_t lse_row_stride;
+    int32_t b, seqlen_q, seqlen_k, h, h_k, h_ratio, d;
+    int32_t is_causal;
+    uint32_t n_q_tiles, n_k_tiles;
+    float scale_log2e;
+    float scale;
+};
+
+hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);
+hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t stream);
+hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t stream);
+hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t stream);
+
+}  // namespace fa

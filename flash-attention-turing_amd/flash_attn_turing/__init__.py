@@ -1,0 +1,51 @@
+"""flash_attn_turing — MI355X (gfx950 / CDNA4) drop-in for ssiu/flash-attention-turing.
+
+Same import surface as the reference's compiled module (reference
+csrc/flash_attn/flash_api.cpp:471-476; used as `from flash_attn_turing import fwd, bwd,
+varlen_fwd, varlen_bwd`, reference test_flash_attn.py:12-17) plus the `flash_attn_func`
+convenience wrapper the reference README documents (README.md:28-48).
+
+The hot path is hand-written HIP in ``csrc/libflash_attn_gfx950.so`` behind the C ABI of
+``include/flash_attn_gfx950.h``.  There is NO fallback: if the compiled pieces are missing the
+import fails loudly (build them with ``python flash-attention-turing_amd/build.py``).
+"""
+import os as _os
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+_CSRC = _os.path.join(_os.path.dirname(_HERE), "csrc")
+LIBRARY_PATH = _os.path.join(_CSRC, "libflash_attn_gfx950.so")
+EXTENSION_PATH = _os.path.join(_HERE, "_C.so")
+
+if not _os.path.exists(LIBRARY_PATH) or not _os.path.exists(EXTENSION_PATH):
+    raise ImportError(
+        "flash_attn_turing: compiled HIP extension not found "
+        f"({LIBRARY_PATH if not _os.path.exists(LIBRARY_PATH) else EXTENSION_PATH}). "
+        "Run `python flash-attention-turing_amd/build.py` (needs hipcc); there is no CPU/PyTorch fallback."
+    )
+
+import torch as _torch  # noqa: E402,F401  (libtorch must be loaded before _C)
+
+from . import _C  # noqa: E402
+from ._C import fwd, bwd, varlen_fwd, varlen_bwd  # noqa: E402,F401
+from .interface import (  # noqa: E402,F401
+    flash_attn_func,
+    flash_attn_varlen_func,
+    FlashAttnFunc,
+    FlashAttnVarlenFunc,
+)
+from .sharding import ShardPlan, plan_shards, shard_tensor  # noqa: E402,F401
+
+__all__ = [
+    "fwd", "bwd", "varlen_fwd", "varlen_bwd",
+    "flash_attn_func", "flash_attn_varlen_func", "FlashAttnFunc", "FlashAttnVarlenFunc",
+    "ShardPlan", "plan_shards", "shard_tensor", "LIBRARY_PATH", "EXTENSION_PATH",
+]
+__version__ = "0.1.0"
+
+
+def abi_version() -> int:
+    return _C.abi_version()
+
+
+def build_info() -> str:
+    return _C.build_info()

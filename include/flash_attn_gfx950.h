@@ -1,0 +1,164 @@
+/*
+ * flash_attn_gfx950.h — C ABI of the MI355X (gfx950 / CDNA4) fused attention library.
+ *
+ * This is the drop-in boundary for the hot path of ssiu/flash-attention-turing
+ * (reference paths below are relative to the reference checkout):
+ *
+ *   reference entry (pybind, csrc/flash_attn/flash_api.cpp)      C-ABI replacement
+ *   ---------------------------------------------------------   -----------------------------
+ *   mha_fwd         flash_api.cpp:156-223  ("fwd",  :472)        fa_mha_fwd
+ *   mha_bwd         flash_api.cpp:228-317  ("bwd",  :473)        fa_mha_bwd
+ *   mha_varlen_fwd  flash_api.cpp:319-381  ("varlen_fwd", :474)  fa_mha_varlen_fwd
+ *   mha_varlen_bwd  flash_api.cpp:383-468  ("varlen_bwd", :475)  fa_mha_varlen_bwd
+ *   run_mha_fwd     flash_api.cpp:139-145  + Flash_fwd_params    fa_run_mha_fwd(fa_fwd_params)
+ *   run_mha_bwd     flash_api.cpp:147-153  + Flash_bwd_params    fa_run_mha_bwd(fa_bwd_params)
+ *                   (src/flash.h:6-76 are the param structs these mirror)
+ *
+ * Only plain pointers, integers and an opaque stream handle cross this boundary: no torch
+ * types, no C++ types.  All pointers are DEVICE pointers (HBM) unless stated otherwise.
+ * The library never allocates or frees device memory and never synchronises the device;
+ * every kernel is enqueued on the `stream` argument (a hipStream_t passed as void*;
+ * NULL = the legacy default stream, which is what the reference launches on,
+ * flash_fwd_launch_template.h:68).
+ *
+ * Conventions (identical to the reference):
+ *   q   : (batch, seqlen_q, nheads,   head_dim)   fp16 or bf16
+ *   k,v : (batch, seqlen_k, nheads_k, head_dim)   same dtype, nheads % nheads_k == 0 (GQA/MQA)
+ *   o   : like q, same dtype.   lse : (batch, nheads, seqlen_q) fp32, natural log.
+ *   scale = 1/sqrt(head_dim) always (flash_fwd_kernel.h:351); causal mask is bottom-right
+ *   aligned (mask.h:172): key j visible to query i iff j - i <= seqlen_k - seqlen_q.
+ *   Rows with no visible key produce o = 0 and lse = 0.0 (flash_fwd_kernel.h:720-728,767-771).
+ *   varlen: q (total_q, nheads, d), k/v (total_k, nheads_k, d) packed, cu_seqlens int32
+ *   device arrays of length batch+1, lse padded to (batch, nheads, max_seqlen_q).
+ *   head_dim in {64, 128} (static_switch.h:29-38); unlike the reference an unsupported
+ *   head_dim is an error, not a silent no-op.
+ *
+ * Every function returns FA_OK (0) or a negative FA_ERR_* code; positive values are
+ * hipError_t codes from the launch.  fa_last_error() gives a human readable message for
+ * the calling thread.
+ */
+#ifndef FLASH_ATTN_GFX950_H
+#define FLASH_ATTN_GFX950_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_ABI_VERSION 1
+
+enum fa_dtype { FA_FP16 = 0, FA_BF16 = 1 };
+
+enum fa_status {
+    FA_OK = 0,
+    FA_ERR_NULL_POINTER = -1,
+    FA_ERR_BAD_SHAPE = -2,       /* rank/size disagreement (reference: TORCH_CHECKs flash_api.cpp:178-183) */
+    FA_ERR_BAD_GQA = -3,         /* nheads % nheads_k != 0 (flash_api.cpp:183) */
+    FA_ERR_BAD_HEADDIM = -4,     /* head_dim not in {64,128} */
+    FA_ERR_BAD_DTYPE = -5,
+    FA_ERR_BAD_STRIDE = -6,      /* last dim not contiguous, misaligned rows, or extent > 2^31 bytes per sequence */
+    FA_ERR_NO_DEVICE = -7
+};
+
+/* Element strides (NOT bytes). The innermost (head_dim) stride is 1 by contract. */
+typedef struct fa_strides {
+    int64_t batch; /* ignored for varlen (packed) tensors */
+    int64_t row;   /* between consecutive sequence positions */
+    int64_t head;  /* between consecutive heads */
+} fa_strides;
+
+/* Mirrors Qkv_params + Flash_fwd_params (reference src/flash.h:6-52). */
+typedef struct fa_fwd_params {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;                 /* (b, h, seqlen_q) contiguous; varlen: (b, h, max_seqlen_q) */
+    const int32_t* cu_seqlens_q; /* NULL for fixed-length batches */
+    const int32_t* cu_seqlens_k;
+    int32_t b;
+    int32_t seqlen_q;           /* varlen: max_seqlen_q */
+    int32_t seqlen_k;           /* varlen: max_seqlen_k */
+    int32_t h;
+    int32_t h_k;
+    int32_t d;
+    int32_t dtype;              /* enum fa_dtype */
+    int32_t is_causal;
+    fa_strides q_stride, k_stride, v_stride, o_stride;
+} fa_fwd_params;
+
+/* Mirrors Flash_bwd_params (reference src/flash.h:55-76). */
+typedef struct fa_bwd_params {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* o;
+    const void* dout;
+    const float* lse;
+    void* dq;
+    void* dk;                   /* (b, seqlen_k, h_k, d): already summed over the GQA group */
+    void* dv;
+    float* dsoftmax_sum;        /* workspace D = rowsum(dO*O), same shape as lse (the reference's do_o) */
+    const int32_t* cu_seqlens_q;
+    const int32_t* cu_seqlens_k;
+    int32_t b;
+    int32_t seqlen_q;
+    int32_t seqlen_k;
+    int32_t h;
+    int32_t h_k;
+    int32_t d;
+    int32_t dtype;
+    int32_t is_causal;
+    fa_strides q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
+} fa_bwd_params;
+
+/* ---- library info ---------------------------------------------------------------------- */
+int fa_abi_version(void);
+const char* fa_last_error(void);
+const char* fa_build_info(void);          /* e.g. "gfx950 hipcc ..." */
+
+/* ---- param-struct entry points (replace run_mha_fwd / run_mha_bwd) ---------------------- */
+int fa_run_mha_fwd(const fa_fwd_params* params, void* stream);
+int fa_run_mha_bwd(const fa_bwd_params* params, void* stream);
+
+/* ---- flat entry points for contiguous tensors (replace mha_fwd / mha_bwd / varlen_*) ---- */
+/* q (b,sq,h,d), k/v (b,sk,hk,d), o (b,sq,h,d), lse (b,h,sq); all contiguous. */
+int fa_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+               int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d,
+               int32_t dtype, int32_t is_causal, void* stream);
+
+int fa_mha_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse,
+               const void* dout, void* dq, void* dk, void* dv, float* dsoftmax_sum,
+               int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d,
+               int32_t dtype, int32_t is_causal, void* stream);
+
+/* q (total_q,h,d), k/v (total_k,hk,d) packed; lse (b,h,max_seqlen_q). */
+int fa_mha_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                      const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                      int32_t b, int32_t max_seqlen_q, int32_t max_seqlen_k,
+                      int32_t h, int32_t h_k, int32_t d,
+                      int32_t dtype, int32_t is_causal, void* stream);
+
+int fa_mha_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse,
+                      const void* dout, void* dq, void* dk, void* dv, float* dsoftmax_sum,
+                      const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                      int32_t b, int32_t max_seqlen_q, int32_t max_seqlen_k,
+                      int32_t h, int32_t h_k, int32_t d,
+                      int32_t dtype, int32_t is_causal, void* stream);
+
+/* D = rowsum(dO * O) alone (replaces flash_bwd_dot_do_o_kernel, flash_bwd_preprocess_kernel.h:23-96);
+ * exposed because it is the one HBM-bound kernel on the path and is measured separately. */
+int fa_bwd_dot_do_o(const fa_bwd_params* params, void* stream);
+
+/* ---- measurement helpers ----------------------------------------------------------------- */
+/* Algorithmic FLOPs of one forward call (4*b*h*sq*sk*d, causal counts only visible pairs);
+ * backward = 2.5x this. Host-only arithmetic, no GPU needed. */
+double fa_fwd_flops(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal);
+/* Algorithmic HBM bytes of one forward call: q,k,v,o once + lse. */
+double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASH_ATTN_GFX950_H */

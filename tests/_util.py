@@ -1,0 +1,133 @@
+"""Shared test helpers: golden-vector loading, error metrics, torch fp32 reference.
+
+The metric set and the tolerances restate the reference's test contract
+(reference test_flash_attn.py:51-71 `_error_metrics`, :407-414 tolerances):
+    max_abs <= 5e-3, mean_abs <= 2e-4, mean_rel <= 1e-2  for O, dQ, dK, dV (fp16).
+bf16 is an extension (the reference is fp16-only); its 8-bit mantissa makes P/dS/outputs ~8x
+coarser, so bf16 tolerances are 8x the fp16 ones and stated here explicitly.
+LSE is not pinned by any reference test; we require |dLSE| <= 1e-3 vs fp32 math.
+"""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TOL = {
+    "fp16": dict(max_abs=5e-3, mean_abs=2e-4, mean_rel=1e-2),
+    "bf16": dict(max_abs=4e-2, mean_abs=1.6e-3, mean_rel=8e-2),
+}
+LSE_TOL = 1e-3
+REL_EPS = 1e-6
+
+
+def error_metrics(x, ref):
+    x = np.asarray(x, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if x.size == 0:
+        return dict(max_abs=0.0, mean_abs=0.0, mean_rel=0.0)
+    diff = np.abs(x - ref)
+    rel = diff / np.maximum(np.abs(ref), REL_EPS)
+    return dict(max_abs=float(diff.max()), mean_abs=float(diff.mean()), mean_rel=float(rel.mean()))
+
+
+def assert_close(x, ref, dtype, name, scale=1.0):
+    assert np.isfinite(np.asarray(x, dtype=np.float64)).all(), f"{name}: non-finite values"
+    m = error_metrics(x, ref)
+    tol = TOL[dtype]
+    for key in ("max_abs", "mean_abs", "mean_rel"):
+        assert m[key] <= tol[key] * scale, f"{name} {key}={m[key]:.3e} > {tol[key] * scale:.3e} ({m})"
+    return m
+
+
+def golden_names(varlen=None):
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    if varlen is True:
+        return [n for n in names if n.startswith("varlen")]
+    if varlen is False:
+        return [n for n in names if not n.startswith("varlen")]
+    return names
+
+
+def _decode(a, is_bf16):
+    """stored inputs: float16 arrays, or int16 bit patterns for bf16 -> float32 values"""
+    if is_bf16:
+        return (a.astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
+    return a.astype(np.float32)
+
+
+def load_golden(name):
+    z = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    if "q" not in z:  # c1_causal shares its inputs with c1_noncausal
+        src = np.load(os.path.join(GOLDEN_DIR, "c1_noncausal.npz"))
+        for k in ("q", "k", "v", "dout"):
+            z[k] = src[k]
+    b, sq, sk, h, hk, d, causal, is_bf16, sub = (int(x) for x in z["meta"])
+    g = dict(name=name, b=b, sq=sq, sk=sk, h=h, hk=hk, d=d, causal=bool(causal),
+             dtype="bf16" if is_bf16 else "fp16", sub=sub, varlen="cu_seqlens_q" in z)
+    for k in ("q", "k", "v", "dout"):
+        g[k] = _decode(z[k], is_bf16)
+    for k in ("o", "dq", "dk", "dv", "lse"):
+        g[k] = z[k]
+    if g["varlen"]:
+        g["cu_seqlens_q"], g["cu_seqlens_k"] = z["cu_seqlens_q"], z["cu_seqlens_k"]
+    return g
+
+
+def subsample(g, o=None, dq=None, dk=None, dv=None, lse=None):
+    """apply the golden file's row subsampling to full results"""
+    s = g["sub"]
+    out = []
+    for t, is_lse in ((o, False), (dq, False), (dk, False), (dv, False), (lse, True)):
+        if t is None:
+            out.append(None)
+        elif g["varlen"]:
+            out.append(t)
+        else:
+            out.append(t[:, :, ::s] if is_lse else t[:, ::s])
+    return out
+
+
+def torch_dtype(name):
+    import torch
+
+    return torch.float16 if name == "fp16" else torch.bfloat16
+
+
+def to_device(arr, dtype_name, device):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device=device, dtype=torch_dtype(dtype_name))
+
+
+def torch_attention_ref(q, k, v, dout=None, causal=False):
+    """Plain PyTorch fp32 statement of the attention contract on the
+    tensors' own device.  q (b,sq,h,d), k/v (b,sk,hk,d) any float dtype -> fp32 O, LSE
+    (dead rows: O = 0, LSE = 0) and, if dout is given, dQ, dK, dV."""
+    import torch
+
+    qf = q.detach().float().requires_grad_(dout is not None)
+    kf = k.detach().float().requires_grad_(dout is not None)
+    vf = v.detach().float().requires_grad_(dout is not None)
+    b, sq, h, d = qf.shape
+    sk, hk = kf.shape[1], kf.shape[2]
+    ratio = h // hk
+    qt = qf.permute(0, 2, 1, 3)
+    kt = kf.permute(0, 2, 1, 3).repeat_interleave(ratio, dim=1)
+    vt = vf.permute(0, 2, 1, 3).repeat_interleave(ratio, dim=1)
+    s = torch.matmul(qt, kt.transpose(-1, -2)) * (1.0 / d ** 0.5)
+    if causal:
+        i = torch.arange(sq, device=q.device).view(-1, 1)
+        j = torch.arange(sk, device=q.device).view(1, -1)
+        s = s.masked_fill(j - i > sk - sq, float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    dead = torch.isinf(lse)
+    p = torch.exp(s - torch.where(dead, torch.zeros_like(lse), lse).unsqueeze(-1))
+    p = torch.where(dead.unsqueeze(-1), torch.zeros_like(p), p)
+    o = torch.matmul(p, vt).permute(0, 2, 1, 3)
+    lse = torch.where(dead, torch.zeros_like(lse), lse)
+    if dout is None:
+        return o.detach(), lse.detach()
+    dq, dk, dv = torch.autograd.grad(o, (qf, kf, vf), dout.detach().float())
+    return o.detach(), lse.detach(), dq, dk, dv
