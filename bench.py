@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X attention path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward pass of the hot path (C ABI `fa_mha_fwd`, include/flash_attn_gfx950.h)
+over one batch of synthetic N(0,1) inputs that are already resident in HBM.  Workload at every N:
+BASELINE.json configs[2] per GPU — forward, b=4, seq=16384, h=32, d=128, fp16, causal — the
+configuration the metric ("attention fwd TFLOP/s & % MFMA peak, b4 h32 d128 seq16k") is quoted
+on.  Multi-GPU is weak scaling over independent (batch, head) problems: every rank owns its own
+b=4 shard (N=8 is BASELINE configs[4]'s b=32), no data-path collective; the only
+communication is the timing barrier and a MAX all-reduce of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): `value` = whole-job
+TFLOP/s using the ALGORITHMIC FLOPs of SURVEY.md §8(d) (4*b*h*sq*sk*d, x1/2 causal),
+`roofline` for the dominant kernel (fa_fwd_kernel) from HIP-event timing on the launch stream,
+`cpu_baseline` = the CPU oracle (oracle/, the checker, never the product) timed on a bounded
+sample on rank 0 at N=1, plus PyTorch SDPA's CPU math path at BASELINE configs[0] as the
+north_star asks.  `extra` carries the other BASELINE configs measured after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "flash-attention-turing_amd"))
+sys.path.insert(0, ROOT)
+
+PEAK_DENSE_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_GBPS = 8000.0
+
+WORKLOADS = {
+    # name: (b, seq, h, h_k, d, dtype, causal, backward)
+    "c3": (4, 16384, 32, 32, 128, "fp16", True, False),    # BASELINE configs[2]  (headline)
+    "c2": (4, 4096, 32, 32, 128, "fp16", False, False),    # BASELINE configs[1]
+    "c4": (4, 8192, 32, 32, 128, "bf16", False, True),     # BASELINE configs[3]  fwd+bwd
+    "c5shard": (4, 16384, 32, 32, 128, "fp16", False, False),  # one GPU's share of configs[4]
+}
+
+
+def fwd_flops(b, sq, sk, h, d, causal):
+    """4*b*h*sq*sk*d, halved for causal (sq == sk)."""
+    f = 4.0 * b * h * sq * sk * d
+    return f * 0.5 if causal else f
+
+
+def fwd_bytes(b, sq, sk, h, hk, d):
+    return 2.0 * (b * sq * h * d * 2.0) + 2.0 * (b * sk * hk * d * 2.0) + b * h * sq * 4.0
+
+
+class Dist:
+    """Minimal one-process-per-GPU harness: env-driven init, barrier, MAX / SUM reductions."""
+
+    def __init__(self, backend):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = backend
+        self.enabled = self.world > 1
+        if self.enabled:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def _tensor(self, x, device):
+        import torch
+
+        return torch.tensor([x], dtype=torch.float64, device=device if self.backend == "nccl" else "cpu")
+
+    def barrier(self, device=None):
+        if self.enabled:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+
+    def reduce_max(self, x, device=None):
+        if not self.enabled:
+            return x
+        t = self._tensor(x, device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(self, x, device=None):
+        if not self.enabled:
+            return x
+        t = self._tensor(x, device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.enabled:
+            self.dist.destroy_process_group()
+
+
+def timed_region(step_fn, steps, warmup, dist, sync_fn, device=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
+    sides; returns (max-over-ranks wall seconds for the K steps, local wall seconds)."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    dist.barrier(device)
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    dist.barrier(device)
+    sync_fn()
+    local = time.perf_counter() - t0
+    return dist.reduce_max(local, device), local
+
+
+def make_inputs(torch, device, b, s, h, hk, d, dtype, seed, backward):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    q = torch.randn(b, s, h, d, device=device, dtype=tdt, generator=gen)
+    k = torch.randn(b, s, hk, d, device=device, dtype=tdt, generator=gen)
+    v = torch.randn(b, s, hk, d, device=device, dtype=tdt, generator=gen)
+    t = dict(q=q, k=k, v=v, o=torch.empty_like(q), lse=torch.empty(b, h, s, device=device, dtype=torch.float32))
+    if backward:
+        t.update(dout=torch.randn(b, s, h, d, device=device, dtype=tdt, generator=gen), dq=torch.empty_like(q),
+                 dk=torch.empty_like(k), dv=torch.empty_like(v), dsum=torch.empty_like(t["lse"]))
+    return t
+
+
+def event_time_ms(torch, fn, iters):
+    """average ms per call, HIP events on torch's current stream (the stream the C ABI launches on)"""
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def cpu_baseline(args):
+    """CPU oracle (kind 'port') on a bounded sample of the headline workload + torch SDPA math path."""
+    import numpy as np
+    import torch
+    from oracle import attn_oracle as A
+
+    b, s, h, d = 1, args.cpu_sample_seq, A.num_threads(), 128      # one head per host thread
+    rng = np.random.default_rng(0)
+    q, k, v = (A.round_lp(rng.standard_normal((b, s, h, d)), A.ROUND_FP16) for _ in range(3))
+    t0 = time.perf_counter()
+    A.attn_fwd(q, k, v, causal=True, round_mode=A.ROUND_FP16)
+    dt = time.perf_counter() - t0
+    out = {
+        "value": fwd_flops(b, s, s, h, d, True) / dt / 1e12, "unit": "TFLOP/s", "cores": A.num_threads(), "kind": "port",
+        "sample": f"oracle/attn_oracle.c forward, b={b} h={h} seq={s} d={d} fp16-rounded causal "
+                  f"(same per-head problem as the headline, shortened from seq 16384), {dt:.1f} s",
+    }
+    # north_star: PyTorch SDPA CPU math path at BASELINE configs[0] (b1 s512 h4 d128 fp32), same run
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+
+    qt, kt, vt = (torch.randn(1, 4, 512, 128) for _ in range(3))
+    with sdpa_kernel(SDPBackend.MATH):
+        for _ in range(3):
+            torch.nn.functional.scaled_dot_product_attention(qt, kt, vt)
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            torch.nn.functional.scaled_dot_product_attention(qt, kt, vt)
+        dt = (time.perf_counter() - t0) / n
+    out["sdpa_math_cpu"] = {"config": "b1 s512 h4 d128 fp32 non-causal (BASELINE configs[0])", "ms": dt * 1e3,
+                            "tflops": fwd_flops(1, 512, 512, 4, 128, False) / dt / 1e12,
+                            "threads": torch.get_num_threads(), "host_cores": os.cpu_count()}
+    return out
+
+
+def run_fake(args, dist):
+    """--fake-step: no GPU, no kernels — exercises sharding + timing aggregation under gloo (CPU tests)."""
+    from flash_attn_turing.sharding import plan_shards
+
+    plan = plan_shards(4 * dist.world, 32, 32, dist.world)[dist.rank]
+    step = lambda: time.sleep(0.002 * (1 + dist.rank))
+    wall, local = timed_region(step, args.steps, args.warmup, dist, lambda: None)
+    units = dist.reduce_sum(float(plan.n_units))
+    if dist.rank == 0:
+        print(json.dumps({"metric": "fake_units_per_s", "value": units * args.steps / wall, "unit": "units/s",
+                          "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": wall / args.steps * 1e3, "units_total": units, "local_ms": local * 1e3}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--fake-step", action="store_true", help="CPU-only harness self-test (no kernels)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-seq", type=int, default=4096)
+    args = ap.parse_args()
+
+    dist = Dist("gloo" if args.fake_step else args.backend)
+    if dist.world != args.gpus and dist.world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dist.world}")
+    if args.gpus > 1 and dist.world == 1:
+        raise SystemExit("for --gpus N>1 launch one rank per GPU with torch.distributed.run (see module docstring)")
+    if args.fake_step:
+        run_fake(args, dist)
+        dist.close()
+        return
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path is HIP-only, there is no CPU fallback")
+    from flash_attn_turing import capi   # fails loudly if the HIP build is missing
+
+    device = torch.device("cuda", dist.local_rank)
+    torch.cuda.set_device(device)
+    b, s, h, hk, d, dtype, causal, backward = WORKLOADS[args.workload]
+    t = make_inputs(torch, device, b, s, h, hk, d, dtype, 1234 + dist.rank, backward)
+
+    def step():
+        capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
+        if backward:
+            capi.mha_bwd(t["q"], t["k"], t["v"], t["o"], t["lse"], t["dout"], t["dq"], t["dk"], t["dv"], t["dsum"], causal)
+
+    sync = lambda: torch.cuda.synchronize(device)
+    flops_rank = fwd_flops(b, s, s, h, d, causal) * (3.5 if backward else 1.0)
+    wall, _ = timed_region(step, args.steps, args.warmup, dist, sync, device)
+    ms_per_step = wall / args.steps * 1e3
+    value = flops_rank * dist.world / (wall / args.steps) / 1e12
+
+    # dominant-kernel roofline: forward kernel alone, HIP events on the launch stream
+    fwd_only = lambda: capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
+    k_ms = event_time_ms(torch, fwd_only, max(5, args.steps))
+    k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "fa_fwd_kernel", "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
+                "unit": "TFLOP/s", "frac": k_tflops / PEAK_DENSE_FP16_TFLOPS, "traffic": None,
+                "avg_launch_ms": k_ms, "algorithmic_flops_per_launch": fwd_flops(b, s, s, h, d, causal),
+                "algorithmic_hbm_gbps": fwd_bytes(b, s, s, h, hk, d) / (k_ms * 1e-3) / 1e9}
+
+    extra = {}
+    if not args.no_extra and dist.rank == 0 and dist.world == 1:
+        del t
+        torch.cuda.empty_cache()
+        for name, (eb, es, eh, ehk, ed, edt, ec, ebwd) in WORKLOADS.items():
+            if name == args.workload:
+                continue
+            et = make_inputs(torch, device, eb, es, eh, ehk, ed, edt, 4321, ebwd)
+            f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], ec)
+            f(); sync()
+            ms = event_time_ms(torch, f, 10)
+            ff = fwd_flops(eb, es, es, eh, ed, ec)
+            extra[name] = {"fwd_ms": ms, "fwd_tflops": ff / ms / 1e9, "fwd_frac_peak": ff / ms / 1e9 / PEAK_DENSE_FP16_TFLOPS}
+            if ebwd:
+                g = lambda: capi.mha_bwd(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"],
+                                         et["dv"], et["dsum"], ec)
+                g(); sync()
+                bms = event_time_ms(torch, g, 5)
+                extra[name].update({"bwd_ms": bms, "bwd_tflops": 2.5 * ff / bms / 1e9,
+                                    "fwd_bwd_tflops": 3.5 * ff / (ms + bms) / 1e9})
+            del et
+            torch.cuda.empty_cache()
+        # seqlen sweep of the reference's published chart (README.md:7-16): b4 h32 d128, no mask
+        sweep = {}
+        for ss in (512, 1024, 2048, 4096, 8192, 16384):
+            et = make_inputs(torch, device, 4, ss, 32, 32, 128, "fp16", 99, False)
+            f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], False)
+            f(); sync()
+            ms = event_time_ms(torch, f, 20 if ss <= 4096 else 8)
+            sweep[str(ss)] = {"ms": ms, "tflops": fwd_flops(4, ss, ss, 32, 128, False) / ms / 1e9}
+            del et
+        extra["sweep_b4_h32_d128_fp16_noncausal"] = sweep
+
+    cpu = None
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if dist.rank == 0:
+        prop = torch.cuda.get_device_properties(device)
+        out = {
+            "metric": "attention_fwd_tflops" if not backward else "attention_fwd_bwd_tflops",
+            "value": value, "unit": "TFLOP/s", "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if dtype == "fp16" else "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5shard': 4}[args.workload] }] per GPU: "
+                                   f"{'fwd+bwd' if backward else 'fwd'} b={b} seq={s} h={h} h_k={hk} d={d} {dtype} "
+                                   f"{'causal' if causal else 'non-causal'}",
+                       "global_batch": b * dist.world, "seq_len": s, "parallelism": f"batch-sharded x{dist.world}, no collective",
+                       "flops_def": "4*b*h*sq*sk*d (x0.5 causal) [SURVEY.md 8d]"},
+            "frac_of_fp16_mfma_peak": value / (PEAK_DENSE_FP16_TFLOPS * dist.world),
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+            "device": {"name": prop.name, "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,
+                       "peak_used_tflops": PEAK_DENSE_FP16_TFLOPS},
+        }
+        print(json.dumps(out))
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@
 // device 0), launch errors surfaced.  This file contains no device code: it is compiled by
 // plain g++ and calls the C ABI in include/flash_attn_gfx950.h; PyTorch is only plumbing
 // (allocation, streams).
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -83,7 +83,7 @@ std::vector<at::Tensor> mha_fwd(at::Tensor q, at::Tensor k, at::Tensor v, bool i
     TORCH_CHECK(k.size(3) == head_size && v.size(3) == head_size, "q/k/v head_dim must match");
     TORCH_CHECK(num_heads_k > 0 && num_heads % num_heads_k == 0, "num_heads_q must be divisible by num_heads_k for GQA/MQA");
 
-    c10::hip::HIPGuard guard(q.device());
+    c10::DeviceGuard guard(q.device());   // resolves to the ROCm (cuda-masquerading) guard impl
     q = dense_last(q); k = dense_last(k); v = dense_last(v);
     // every element of o and l is written by the kernel (dead rows included), so no zero fill
     at::Tensor o = torch::empty(q.sizes(), q.options());
@@ -117,7 +117,7 @@ std::vector<at::Tensor> mha_bwd(at::Tensor q, at::Tensor k, at::Tensor v, at::Te
     TORCH_CHECK(l.scalar_type() == torch::kFloat32 && l.dim() == 3 && l.size(0) == batch_size && l.size(1) == num_heads &&
                     l.size(2) == seqlen_q, "l must be fp32 with shape [batch_size, nheads_q, seqlen_q]");
 
-    c10::hip::HIPGuard guard(q.device());
+    c10::DeviceGuard guard(q.device());   // resolves to the ROCm (cuda-masquerading) guard impl
     q = dense_last(q); k = dense_last(k); v = dense_last(v); out = dense_last(out); dout = dense_last(dout);
     l = l.contiguous();
     at::Tensor dq = torch::empty(q.sizes(), q.options());
@@ -154,7 +154,7 @@ std::vector<at::Tensor> mha_varlen_fwd(at::Tensor q, at::Tensor k, at::Tensor v,
     TORCH_CHECK(max_seqlen_q >= 0 && max_seqlen_k >= 0, "max_seqlen_q/max_seqlen_k must be non-negative");
     const int64_t num_heads = q.size(1), num_heads_k = k.size(1), head_size = q.size(2);
 
-    c10::hip::HIPGuard guard(q.device());
+    c10::DeviceGuard guard(q.device());   // resolves to the ROCm (cuda-masquerading) guard impl
     q = dense_last(q); k = dense_last(k); v = dense_last(v);
     // tokens past cu_seqlens_q[-1] belong to no sequence and are not touched by the kernel: keep
     // the reference's zero fill (flash_api.cpp:351) for them
@@ -196,7 +196,7 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     TORCH_CHECK(l.scalar_type() == torch::kFloat32, "l must be fp32");
     TORCH_CHECK(out.scalar_type() == q.scalar_type() && dout.scalar_type() == q.scalar_type(), "out/dout dtype must match q");
 
-    c10::hip::HIPGuard guard(q.device());
+    c10::DeviceGuard guard(q.device());   // resolves to the ROCm (cuda-masquerading) guard impl
     q = dense_last(q); k = dense_last(k); v = dense_last(v); out = dense_last(out); dout = dense_last(dout);
     l = l.contiguous();
     at::Tensor dq = torch::zeros_like(q);

@@ -1,0 +1,116 @@
+"""ctypes binding of the C ABI in include/flash_attn_gfx950.h (libflash_attn_gfx950.so).
+
+This is the binding a non-PyTorch host (or the reference's maintainers)
+would write: plain device pointers and sizes, a stream handle, integer status codes.  The
+PyTorch host module (`_C`) is built on the same entry points in C++; this module exists so
+tests and bench.py can drive and time the C ABI directly.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libflash_attn_gfx950.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "flash_attn_gfx950.h")
+
+FA_FP16, FA_BF16 = 0, 1
+FA_OK = 0
+FA_ERR_NULL_POINTER, FA_ERR_BAD_SHAPE, FA_ERR_BAD_GQA, FA_ERR_BAD_HEADDIM, FA_ERR_BAD_DTYPE, FA_ERR_BAD_STRIDE = -1, -2, -3, -4, -5, -6
+
+_vp, _i32, _fp = ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p
+
+
+class Strides(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int64), ("row", ctypes.c_int64), ("head", ctypes.c_int64)]
+
+
+class FwdParams(ctypes.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("lse", _vp),
+                ("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp),
+                ("b", _i32), ("seqlen_q", _i32), ("seqlen_k", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
+                ("dtype", _i32), ("is_causal", _i32),
+                ("q_stride", Strides), ("k_stride", Strides), ("v_stride", Strides), ("o_stride", Strides)]
+
+
+class BwdParams(ctypes.Structure):
+    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("dout", _vp), ("lse", _vp),
+                ("dq", _vp), ("dk", _vp), ("dv", _vp), ("dsoftmax_sum", _vp),
+                ("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp),
+                ("b", _i32), ("seqlen_q", _i32), ("seqlen_k", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
+                ("dtype", _i32), ("is_causal", _i32),
+                ("q_stride", Strides), ("k_stride", Strides), ("v_stride", Strides), ("o_stride", Strides),
+                ("do_stride", Strides), ("dq_stride", Strides), ("dk_stride", Strides), ("dv_stride", Strides)]
+
+
+_lib = None
+
+
+def declared_functions():
+    """names of every function declared in the public header"""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(fa_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBRARY_PATH):
+            raise ImportError(f"{LIBRARY_PATH} missing: run `python flash-attention-turing_amd/build.py`")
+        L = ctypes.CDLL(LIBRARY_PATH)
+        L.fa_abi_version.restype = ctypes.c_int
+        L.fa_last_error.restype = ctypes.c_char_p
+        L.fa_build_info.restype = ctypes.c_char_p
+        L.fa_run_mha_fwd.argtypes = [ctypes.POINTER(FwdParams), _vp]
+        L.fa_run_mha_bwd.argtypes = [ctypes.POINTER(BwdParams), _vp]
+        L.fa_bwd_dot_do_o.argtypes = [ctypes.POINTER(BwdParams), _vp]
+        L.fa_mha_fwd.argtypes = [_vp] * 5 + [_i32] * 8 + [_vp]
+        L.fa_mha_bwd.argtypes = [_vp] * 10 + [_i32] * 8 + [_vp]
+        L.fa_mha_varlen_fwd.argtypes = [_vp] * 7 + [_i32] * 8 + [_vp]
+        L.fa_mha_varlen_bwd.argtypes = [_vp] * 12 + [_i32] * 8 + [_vp]
+        for n in ("fa_run_mha_fwd", "fa_run_mha_bwd", "fa_bwd_dot_do_o", "fa_mha_fwd", "fa_mha_bwd",
+                  "fa_mha_varlen_fwd", "fa_mha_varlen_bwd"):
+            getattr(L, n).restype = ctypes.c_int
+        L.fa_fwd_flops.argtypes = [_i32] * 6
+        L.fa_fwd_flops.restype = ctypes.c_double
+        L.fa_fwd_bytes.argtypes = [_i32] * 6
+        L.fa_fwd_bytes.restype = ctypes.c_double
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().fa_last_error().decode()
+
+
+def check(rc: int):
+    if rc != FA_OK:
+        raise RuntimeError(f"flash_attn_gfx950: {last_error()} [code {rc}]")
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+
+    return {torch.float16: FA_FP16, torch.bfloat16: FA_BF16}[torch_dtype]
+
+
+def mha_fwd(q, k, v, o, lse, causal, stream=None):
+    """Contiguous torch tensors in, kernels enqueued on `stream` (default: torch's current stream)."""
+    import torch
+
+    b, sq, h, d = q.shape
+    sk, hk = k.shape[1], k.shape[2]
+    s = torch.cuda.current_stream(q.device).cuda_stream if stream is None else stream
+    check(lib().fa_mha_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(),
+                           b, sq, sk, h, hk, d, dtype_code(q.dtype), int(causal), s))
+
+
+def mha_bwd(q, k, v, o, lse, dout, dq, dk, dv, dsum, causal, stream=None):
+    import torch
+
+    b, sq, h, d = q.shape
+    sk, hk = k.shape[1], k.shape[2]
+    s = torch.cuda.current_stream(q.device).cuda_stream if stream is None else stream
+    check(lib().fa_mha_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(),
+                           b, sq, sk, h, hk, d, dtype_code(q.dtype), int(causal), s))
