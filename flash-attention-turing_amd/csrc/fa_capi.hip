@@ -62,6 +62,9 @@ extern "C" {
 
 int fa_abi_version(void) { return FA_ABI_VERSION; }
 const char* fa_last_error(void) { return g_err; }
+/* debug / A-B timing hook, not part of the public header: selects the forward schedule */
+void fa_debug_set_fwd_impl(int impl) { fa::set_fwd_impl(impl); }
+
 const char* fa_build_info(void) { return "flash_attn_gfx950 abi=1 arch=gfx950 mfma=32x32x16 wave64 built " __DATE__; }
 
 double fa_fwd_flops(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t d, int32_t is_causal) {

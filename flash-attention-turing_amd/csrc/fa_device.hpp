@@ -116,6 +116,23 @@ FA_DEV uint32_t lds_tile_off(uint32_t row, uint32_t slot /* 16-byte slot in row,
     }
 }
 
+// Inverse of the slot swizzle: which logical 16-byte slot of `row` lives at physical slot `phys`
+// (the XOR is an involution).  Used by the LDS-DMA staging, whose LDS image is lane-linear, so the
+// swizzle has to be applied on the global SOURCE address instead (cdna guide rule 21).
+template <int D>
+FA_DEV uint32_t lds_tile_logical_slot(uint32_t row, uint32_t phys) {
+    if constexpr (D == 128) return phys ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    else return phys ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+
+// Asynchronous HBM -> LDS copy (buffer_load_dwordx4 ... lds): every lane moves 16 bytes from
+// rsrc[voffset] to lds_base + 16 * lane (wave-uniform base, lane-linear image); out-of-range
+// source addresses write zeros.  Completion is tracked by vmcnt; hipcc drains it at the next
+// __syncthreads().
+FA_DEV void dma16_to_lds(rsrc_t r, uint32_t voffset, FA_LDS char* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (FA_LDS void*)lds_base, 16, voffset, 0, 0, 0);
+}
+
 FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }
 FA_DEV void lds_write16(FA_LDS char* base, uint32_t off, u32x4 v) { *(FA_LDS u32x4*)(base + off) = v; }
 FA_DEV void lds_write8(FA_LDS char* base, uint32_t off, u32x2 v) { *(FA_LDS u32x2*)(base + off) = v; }

@@ -52,6 +52,7 @@ struct BwdKernelParams {
 };
 
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);
+void set_fwd_impl(int impl);   // -1 = env/default, 0 = simple, 1 = ping-pong (debug / A-B timing only)
 hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t stream);
