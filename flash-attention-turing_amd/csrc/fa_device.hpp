@@ -133,6 +133,30 @@ FA_DEV void dma16_to_lds(rsrc_t r, uint32_t voffset, FA_LDS char* lds_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (FA_LDS void*)lds_base, 16, voffset, 0, 0, 0);
 }
 
+// The same copy issued from inline asm so that hipcc does NOT know about it: the compiler treats
+// an LDS-DMA it can see as a store that may alias every later LDS read and parks
+// "s_waitcnt vmcnt(0)" in front of the next ds_read, which serialises the HBM/L2 latency with
+// the matrix phase.  The caller owns the bookkeeping (cdna guide 5.7): one explicit
+// "s_waitcnt vmcnt(0)" and a workgroup barrier between this and the first ds_read of the data.
+// srd: buffer descriptor words in SGPRs; lds_byte_addr: wave-uniform LDS byte address (M0).
+typedef int srd_t __attribute__((ext_vector_type(4)));
+FA_DEV srd_t make_srd(const void* base, uint32_t num_bytes) {
+    const uint64_t b = (uint64_t)base;
+    srd_t s;
+    s.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    s.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));   // stride 0, no swizzle
+    s.z = __builtin_amdgcn_readfirstlane((int)num_bytes);
+    s.w = 0x00020000;                                                              // raw 32-bit data format
+    return s;
+}
+FA_DEV uint32_t lds_addr(const FA_LDS char* p) { return (uint32_t)(uintptr_t)p; }
+FA_DEV void dma16_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds_byte_addr) {
+    // s_nop 4: SGPRs of the descriptor / M0 source may have just been written by v_readfirstlane
+    // or SALU; s_nop 0 after the M0 write (hazard tables 11 / 38).
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
+}
+
 FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }
 FA_DEV void lds_write16(FA_LDS char* base, uint32_t off, u32x4 v) { *(FA_LDS u32x4*)(base + off) = v; }
 FA_DEV void lds_write8(FA_LDS char* base, uint32_t off, u32x2 v) { *(FA_LDS u32x2*)(base + off) = v; }

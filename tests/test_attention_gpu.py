@@ -29,7 +29,7 @@ def run_hip(g_or_tensors, gpu, causal, dtype, varlen=None):
     return tuple(t.float().cpu().numpy() for t in (o, lse, dq, dk, dv))
 
 
-@pytest.fixture(params=["pp", "simple"])
+@pytest.fixture(params=["pp", "simple", "sp"])
 def fwd_impl(request):
     """both forward schedules (ping-pong = shipped default, simple = bisecting aid) must be correct"""
     from flash_attn_turing import capi
