@@ -143,6 +143,47 @@ def event_time_ms(torch, fn, iters):
     return start.elapsed_time(end) / iters
 
 
+def hbm_traffic_from_profile(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  PMC collection cannot run inside the timed process, so this is the per-round profile value
+    (profiles/rNN_hbm_traffic.json), or None when no profile of this workload is committed."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("workload") == workload:
+                return float(d["traffic_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
+
+
+def measured_mfma_ceiling():
+    """tools/clockbench (built by __graft_entry__.build()): sustained clock and TFLOP/s of a chip-wide
+    back-to-back MFMA loop on random operands = what the MFMA roof really is on this box under its
+    power limit.  Reported next to the nominal 2.5 PFLOP/s, never used as `peak`."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "clockbench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+        best = None
+        for line in out.splitlines():
+            if line.startswith("MFMA only"):
+                ghz = float(line.split("->")[1].split("GHz")[0])
+                tf = float(line.split(";")[1].split("TFLOP")[0])
+                if best is None or tf > best["tflops"]:
+                    best = {"tflops": tf, "clock_ghz": ghz, "what": line.split("  ")[0].strip()}
+        return best
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """CPU oracle (kind 'port') on a bounded sample of the headline workload + torch SDPA math path."""
     import numpy as np
@@ -241,8 +282,9 @@ def main():
     fwd_only = lambda: capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
     k_ms = event_time_ms(torch, fwd_only, max(5, args.steps))
     k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "fa_fwd_kernel", "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
-                "unit": "TFLOP/s", "frac": k_tflops / PEAK_DENSE_FP16_TFLOPS, "traffic": None,
+    roofline = {"bound": "mfma", "kernel": "fa_fwd_pp_kernel", "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
+                "unit": "TFLOP/s", "frac": k_tflops / PEAK_DENSE_FP16_TFLOPS,
+                "traffic": hbm_traffic_from_profile(args.workload) if dist.rank == 0 else None,
                 "avg_launch_ms": k_ms, "algorithmic_flops_per_launch": fwd_flops(b, s, s, h, d, causal),
                 "algorithmic_hbm_gbps": fwd_bytes(b, s, s, h, hk, d) / (k_ms * 1e-3) / 1e9}
 
@@ -283,6 +325,10 @@ def main():
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
+    ceiling = measured_mfma_ceiling() if (dist.rank == 0 and dist.world == 1 and not args.no_extra) else None
+    if ceiling is not None:
+        roofline["sustained_mfma_peak_measured"] = ceiling
+        roofline["frac_of_sustained_measured"] = k_tflops / ceiling["tflops"]
     if dist.rank == 0:
         prop = torch.cuda.get_device_properties(device)
         out = {
@@ -297,7 +343,7 @@ def main():
                        "flops_def": "4*b*h*sq*sk*d (x0.5 causal) [SURVEY.md 8d]"},
             "frac_of_fp16_mfma_peak": value / (PEAK_DENSE_FP16_TFLOPS * dist.world),
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
-            "device": {"name": prop.name, "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,
+            "device": {"name": prop.name or getattr(prop, "gcnArchName", ""), "arch": getattr(prop, "gcnArchName", ""), "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,
                        "peak_used_tflops": PEAK_DENSE_FP16_TFLOPS},
         }
         print(json.dumps(out))

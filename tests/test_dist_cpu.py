@@ -1,0 +1,63 @@
+"""CPU: the one-process-per-GPU harness of bench.py (env-driven init, barrier-bracketed timing,
+MAX-over-ranks time, SUM of units) under gloo with world_size 2, and the batch x head shard plan
+each rank would take.  No kernels run (`--fake-step`); the GPU path uses the same `Dist` /
+`timed_region` code with backend nccl (= RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, extra=()):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5",
+                                       "--warmup", "1", "--fake-step", *extra], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    return outs
+
+
+def test_two_rank_gloo_timing_and_unit_aggregation():
+    outs = _launch(2)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly one JSON line"
+    assert not any(l.startswith("{") for l in outs[1][0].splitlines()), "only rank 0 prints"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 1
+    # fake step sleeps 2 ms * (1 + rank): the reported time must be the MAX over ranks (rank 1: >= 4 ms/step)
+    assert r["ms_per_step"] >= 4.0
+    assert r["local_ms"] <= r["ms_per_step"] * 5 + 1e-6
+    # weak scaling: every rank owns b=4 x h=32 independent (batch, head) problems
+    assert r["units_total"] == 2 * 4 * 32
+    assert abs(r["value"] - r["units_total"] * 5 / (r["ms_per_step"] * 5e-3)) / r["value"] < 1e-6
+
+
+def test_single_process_fake_step():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fake-step", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["units_total"] == 4 * 32
+
+
+def test_gpus_flag_must_match_world_size():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fake-step", "--gpus", "2"], env=env,
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)

@@ -1,0 +1,172 @@
+"""GPU: size-independent properties at BASELINE.json's full sizes (too big for the CPU oracle),
+plus direct calls through the C ABI (ctypes, flat entry points)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import _util as U
+
+pytestmark = pytest.mark.gpu
+
+C2 = (4, 4096, 32, 128)      # BASELINE configs[1]
+C3 = (4, 16384, 32, 128)     # BASELINE configs[2]
+
+
+def _rand(gpu, shape, dtype=torch.float16, seed=0):
+    gen = torch.Generator(device=gpu).manual_seed(seed)
+    return torch.randn(*shape, device=gpu, dtype=dtype, generator=gen)
+
+
+@pytest.mark.parametrize("shape,causal", [(C2, False), (C3, True)])
+def test_softmax_rows_sum_to_one_and_lse_consistent(gpu, shape, causal):
+    """V = ones  =>  O = 1 exactly where a key is visible (P rows sum to 1 within fp16 rounding of P);
+    and LSE must equal an fp32 logsumexp recomputed for sampled rows."""
+    import flash_attn_turing as F
+
+    b, s, h, d = shape
+    q, k = _rand(gpu, (b, s, h, d), seed=1), _rand(gpu, (b, s, h, d), seed=2)
+    o, lse = F.fwd(q, k, torch.ones_like(k), causal)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    assert (o.float() - 1.0).abs().max().item() <= 2e-3
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, 257, s // 2, s - 2, s - 1], device=gpu)
+    for bi, hi in ((0, 0), (b - 1, h - 1), (1, 7)):
+        sc = (q[bi, rows, hi].float() @ k[bi, :, hi].float().T) / d ** 0.5
+        if causal:
+            sc = sc.masked_fill(torch.arange(s, device=gpu)[None, :] > rows[:, None], float("-inf"))
+        assert (torch.logsumexp(sc, -1) - lse[bi, hi, rows]).abs().max().item() <= U.LSE_TOL
+
+
+def test_causal_first_rows_copy_v(gpu):
+    """causal, sq == sk: query 0 sees only key 0 => O[0] == V[0] bit-exactly; query 1 is a 2-key blend."""
+    import flash_attn_turing as F
+
+    b, s, h, d = C3
+    q, k, v = (_rand(gpu, (b, s, h, d), seed=i) for i in (3, 4, 5))
+    o, lse = F.fwd(q, k, v, True)
+    assert torch.equal(o[:, 0], v[:, 0])
+    s0 = (q[:, 0].float() * k[:, 0].float()).sum(-1) / d ** 0.5
+    assert (lse[:, :, 0] - s0).abs().max().item() <= 1e-4
+
+
+def test_key_permutation_invariance_noncausal(gpu):
+    """softmax attention does not depend on the order of the keys (non-causal): permuting K and V rows
+    changes tile membership and the online-softmax path, never the result (up to fp32 summation order)."""
+    import flash_attn_turing as F
+
+    b, s, h, d = C2
+    q, k, v = (_rand(gpu, (b, s, h, d), seed=i) for i in (6, 7, 8))
+    perm = torch.randperm(s, device=gpu, generator=torch.Generator(device=gpu).manual_seed(9))
+    o1, l1 = F.fwd(q, k, v, False)
+    o2, l2 = F.fwd(q, k[:, perm].contiguous(), v[:, perm].contiguous(), False)
+    assert (o1.float() - o2.float()).abs().max().item() <= 2e-3
+    assert (l1 - l2).abs().max().item() <= 1e-4
+
+
+def test_linearity_in_v_and_in_dout(gpu):
+    """O is linear in V; dQ, dK, dV are linear in dO (fixed q, k, v)."""
+    import flash_attn_turing as F
+
+    b, s, h, d = 2, 4096, 16, 128
+    q, k, v1, v2 = (_rand(gpu, (b, s, h, d), seed=i) for i in (10, 11, 12, 13))
+    o1, _ = F.fwd(q, k, v1, True)
+    o2, _ = F.fwd(q, k, v2, True)
+    o12, _ = F.fwd(q, k, (v1.float() * 0.5 + v2.float() * 0.25).half(), True)
+    assert (o12.float() - (0.5 * o1.float() + 0.25 * o2.float())).abs().max().item() <= 3e-3
+    o, lse = F.fwd(q, k, v1, True)
+    d1, d2 = _rand(gpu, (b, s, h, d), seed=14), _rand(gpu, (b, s, h, d), seed=15)
+    g1 = F.bwd(q, k, v1, o, lse, d1, True)
+    g2 = F.bwd(q, k, v1, o, lse, d2, True)
+    g12 = F.bwd(q, k, v1, o, lse, (d1.float() * 0.5 + d2.float() * 0.5).half(), True)
+    for a, b_, c_ in zip(g1, g2, g12):
+        assert (c_.float() - 0.5 * (a.float() + b_.float())).abs().max().item() <= 6e-3
+
+
+def test_batch_head_sharding_equals_whole_and_is_deterministic(gpu):
+    """The multi-GPU decomposition (independent (batch, head) problems, strided shard views) gives
+    bit-identical results to the unsharded call, and repeated calls are bit-identical."""
+    import flash_attn_turing as F
+
+    b, s, h, hk, d = 4, 2048, 16, 4, 128
+    q = _rand(gpu, (b, s, h, d), seed=16)
+    k, v = _rand(gpu, (b, s, hk, d), seed=17), _rand(gpu, (b, s, hk, d), seed=18)
+    o, lse = F.fwd(q, k, v, True)
+    o_again, lse_again = F.fwd(q, k, v, True)
+    assert torch.equal(o, o_again) and torch.equal(lse, lse_again)
+    for plan in F.plan_shards(b, h, hk, 8):
+        qs, ks, vs = F.shard_tensor(q, plan, False), F.shard_tensor(k, plan, True), F.shard_tensor(v, plan, True)
+        os_, ls_ = F.fwd(qs, ks, vs, True)
+        assert torch.equal(os_, F.shard_tensor(o, plan, False))
+        assert torch.equal(ls_, lse[plan.batch_start:plan.batch_stop, plan.head_start:plan.head_stop])
+
+
+def test_backward_full_size_c4_sanity(gpu):
+    """BASELINE configs[3] shape (bf16, b4 s8192 h32 d128): finite, and dV column sums match the
+    closed form  sum_j dV_j = sum_i dO_i  (every P row sums to 1)."""
+    import flash_attn_turing as F
+
+    b, s, h, d = 4, 8192, 32, 128
+    q, k, v, do = (_rand(gpu, (b, s, h, d), torch.bfloat16, seed=i) for i in (19, 20, 21, 22))
+    o, lse = F.fwd(q, k, v, False)
+    dq, dk, dv = F.bwd(q, k, v, o, lse, do, False)
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t).all()
+    lhs, rhs = dv.float().sum(1), do.float().sum(1)
+    assert ((lhs - rhs).abs().max() / rhs.abs().max()).item() <= 2e-2
+    # softmax shift invariance: sum_j dS_ij = 0  =>  sum over keys of dK weighted ... check dQ.q - dK.k balance
+    a1 = (dq.float() * q.float()).sum((1, 3))
+    a2 = (dk.float() * k.float()).sum((1, 3))
+    assert ((a1 - a2).abs().max() / a1.abs().max().clamp_min(1e-3)).item() <= 5e-2
+
+
+def test_c_abi_flat_entry_points_match_host_module(gpu):
+    """ctypes -> fa_mha_fwd / fa_mha_bwd / fa_mha_varlen_fwd with raw device pointers."""
+    import flash_attn_turing as F
+    from flash_attn_turing import capi
+
+    b, sq, sk, h, hk, d = 2, 300, 389, 4, 2, 128
+    q, do = _rand(gpu, (b, sq, h, d), seed=30), _rand(gpu, (b, sq, h, d), seed=31)
+    k, v = _rand(gpu, (b, sk, hk, d), seed=32), _rand(gpu, (b, sk, hk, d), seed=33)
+    o = torch.full_like(q, float("nan"))
+    lse = torch.full((b, h, sq), float("nan"), device=gpu)
+    capi.mha_fwd(q, k, v, o, lse, True)
+    o_ref, lse_ref = F.fwd(q, k, v, True)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dsum = torch.empty_like(lse)
+    capi.mha_bwd(q, k, v, o, lse, do, dq, dk, dv, dsum, True)
+    r = F.bwd(q, k, v, o, lse, do, True)
+    torch.cuda.synchronize()
+    assert torch.equal(dq, r[0]) and torch.equal(dk, r[1]) and torch.equal(dv, r[2])
+    assert (dsum - (o.float() * do.float()).sum(-1).permute(0, 2, 1)).abs().max().item() <= 1e-3
+    # varlen through the flat entry point == fixed-length call on each sequence
+    L = capi.lib()
+    cu = torch.tensor([0, sq, 2 * sq], device=gpu, dtype=torch.int32)
+    cuk = torch.tensor([0, sk, 2 * sk], device=gpu, dtype=torch.int32)
+    qp, kp, vp = q.reshape(b * sq, h, d), k.reshape(b * sk, hk, d), v.reshape(b * sk, hk, d)
+    op = torch.empty_like(qp)
+    lp = torch.zeros(b, h, sq, device=gpu)
+    s = torch.cuda.current_stream().cuda_stream
+    rc = L.fa_mha_varlen_fwd(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), op.data_ptr(), lp.data_ptr(), cu.data_ptr(), cuk.data_ptr(),
+                             b, sq, sk, h, hk, d, 0, 1, s)
+    assert rc == 0, capi.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(op.reshape(b, sq, h, d), o) and torch.equal(lp, lse)
+    # a bad call reports an error code instead of launching
+    assert L.fa_mha_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), b, sq, sk, 3, 2, d, 0, 0, s) == capi.FA_ERR_BAD_GQA
+
+
+def test_kernels_run_on_the_current_stream(gpu):
+    """work is enqueued on torch's current stream (the reference uses the legacy default stream)."""
+    import flash_attn_turing as F
+
+    q, k, v = (_rand(gpu, (1, 512, 4, 128), seed=i) for i in (40, 41, 42))
+    ref, _ = F.fwd(q, k, v, False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out, _ = F.fwd(q, k, v, False)
+    side.synchronize()
+    assert torch.equal(out, ref)
