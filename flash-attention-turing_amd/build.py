@@ -34,7 +34,11 @@ EXT_PATH = os.path.join(PKG, "_C.so")
 
 HIP_SOURCES = ["fa_fwd.hip", "fa_fwd_pp.hip", "fa_fwd_sp.hip", "fa_bwd.hip", "fa_capi.hip"]
 HIP_HEADERS = ["fa_device.hpp", "fa_params.hpp", os.path.join(INCLUDE, "flash_attn_gfx950.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+# -amdgpu-mfma-vgpr-form: builtin MFMAs keep their result in VGPRs even in kernels that may use the
+# accumulator half of the register file (the dK/dV kernel parks its 128 long-lived accumulator
+# registers in AGPRs through LP<T>::mfma_agpr); without it hipcc selects the AGPR form for every MFMA
+# of such a kernel and shuttles the softmax operands with v_accvgpr_read/write.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
                "-DNDEBUG", "-Wall", "-Wno-unused-function"]
 
 

@@ -11,9 +11,9 @@
 // recomputed in both kernels).  Differences that matter on CDNA4:
 //   * dQ kernel uses the forward's "swapped" layout (lane = query column), so LSE_i and D_i
 //     are lane scalars and dS^T feeds the dQ^T MFMA straight from registers;
-//   * dK/dV kernel uses the un-swapped layout (lane = key column), K/V fragments stay in
-//     registers for the whole Q loop, P and dS feed dV^T / dK^T MFMAs straight from registers,
-//     Q^T / dO^T operands come from hardware transposing LDS reads;
+//   * dK/dV kernel uses the un-swapped layout (lane = key column), P and dS feed the dV^T / dK^T
+//     MFMAs straight from registers, Q^T / dO^T operands come from hardware transposing LDS reads,
+//     the dK^T / dV^T accumulators live in AGPRs;
 //   * the GQA group loop is fused into the dK/dV kernel (the reference materialises per-q-head
 //     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312).
 #include "fa_device.hpp"
@@ -274,27 +274,40 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
 }
 
 // =============================================================================================
-// dK/dV kernel: workgroup = 4 waves = 128 keys of one (batch, kv head); loops over the GQA
-// group's query heads and over 64-row Q/dO tiles.
+// dK/dV kernel: workgroup = 8 waves = 128 keys of one (batch, kv head); loops over the GQA
+// group's query heads and over 64-row Q/dO tiles.  Wave w owns key block kb = w & 3 (32 keys)
+// and the 32-row half qh = w >> 2 of every Q/dO tile; the two q-halves' partial dK^T / dV^T are
+// summed through LDS once, in the epilogue.
+//
+// Register plan (lessons of the first two versions): the 128 long-lived
+// accumulator registers live in AGPRs and are only touched by MFMAs (LP<T>::mfma_agpr, inline
+// asm "+a"); with -amdgpu-mfma-vgpr-form every other MFMA result stays in VGPRs where the softmax
+// VALU uses it directly, so there is no v_accvgpr shuttling; everything else fits 128 VGPRs, so
+// TWO waves share each SIMD (a lone wave per SIMD left every LDS latency exposed: 39 % MFMA
+// utilisation).  K^T / V^T operands are read from the workgroup's resident K/V tiles in LDS, Q/dO
+// tiles arrive by LDS-DMA.
+// LDS: K[128 keys] | V[128 keys] | Q ring[2] | dO ring[2] | stats ring[2]  = 129 KiB.
 // =============================================================================================
-constexpr int kKvThreads = 256;
-constexpr int kKvBlockN = 128;   // keys per workgroup (32 per wave)
-constexpr int kKvBlockM = 64;    // query rows per staged tile
+constexpr int kKvThreads = 512;
+constexpr int kKvBlockN = 128;   // keys per workgroup (32 per key block, 4 key blocks)
+constexpr int kKvBlockM = 64;    // query rows per staged tile (two 32-row halves)
 
 template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kKvThreads, 1) void fa_bwd_dkdv_kernel(const BwdKernelParams p) {
+__global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
+    constexpr int KVB = kKvBlockN * ROWB;                   // the workgroup's K (or V) tile
     constexpr int TILEB = kKvBlockM * ROWB;                 // one Q (or dO) tile
-    constexpr int CPT = (kKvBlockM * SLOTS) / kKvThreads;   // 16B chunks / thread / tile
     constexpr int STATB = 2 * kKvBlockM * 4;                // lse2 + dsum of one tile
-    constexpr int MAINB = (4 * TILEB > 2 * kKvBlockN * ROWB) ? 4 * TILEB : 2 * kKvBlockN * ROWB;
-    // LDS: Q[2] | dO[2] | stats[2]; dK / dV tiles alias Q/dO in the epilogue
-    __shared__ __attribute__((aligned(16))) char smem_raw[MAINB + 2 * STATB];
+    constexpr int OFF_V = KVB, OFF_Q = 2 * KVB, OFF_DO = 2 * KVB + 2 * TILEB, OFF_STAT = 2 * KVB + 4 * TILEB;
+    __shared__ __attribute__((aligned(16))) char smem_raw[OFF_STAT + 2 * STATB];   // the only LDS object
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
-    FA_LDS char* stat = smem + MAINB;
+    FA_LDS char* ktile = smem;
+    FA_LDS char* vtile = smem + OFF_V;
+    FA_LDS char* stat = smem + OFF_STAT;
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave & 3, qh = wave >> 2;             // key block / q-half of this wave
 
     uint32_t tile, bhk;
     decode_block(blockIdx.x, p.n_k_tiles, (uint32_t)(p.b * p.h_k), tile, bhk);
@@ -322,8 +335,8 @@ __global__ __launch_bounds__(kKvThreads, 1) void fa_bwd_dkdv_kernel(const BwdKer
     T* dv_base = uniform_ptr((T*)p.dv_ptr + dv_boff + (k_row0 + n0) * p.dv.row + (int64_t)head_k * p.dv.head);
     const uint32_t k_rowb = (uint32_t)(p.k.row * 2), v_rowb = (uint32_t)(p.v.row * 2), dk_rowb = (uint32_t)(p.dk.row * 2),
                    dv_rowb = (uint32_t)(p.dv.row * 2), q_rowb = (uint32_t)(p.q.row * 2), do_rowb = (uint32_t)(p.dout.row * 2);
-    const rsrc_t k_rs = make_rsrc(k_base, (uint32_t)(keys_here - 1) * k_rowb + ROWB);
-    const rsrc_t v_rs = make_rsrc(v_base, (uint32_t)(keys_here - 1) * v_rowb + ROWB);
+    const srd_t k_srd = make_srd(k_base, (uint32_t)(keys_here - 1) * k_rowb + ROWB);
+    const srd_t v_srd = make_srd(v_base, (uint32_t)(keys_here - 1) * v_rowb + ROWB);
     const rsrc_t dk_rs = make_rsrc(dk_base, (uint32_t)(keys_here - 1) * dk_rowb + ROWB);
     const rsrc_t dv_rs = make_rsrc(dv_base, (uint32_t)(keys_here - 1) * dv_rowb + ROWB);
 
@@ -334,17 +347,26 @@ __global__ __launch_bounds__(kKvThreads, 1) void fa_bwd_dkdv_kernel(const BwdKer
     const int tiles_per_head = max(0, n_q_tiles - qt_begin);
     const int n_iters = tiles_per_head * p.h_ratio;
 
-    const int key_row = wave * 32 + l31;                 // this lane's key inside the 128-key block
-    const int wave_k_lo = n0 + wave * 32, wave_k_hi = wave_k_lo + 31;
+    const int key_row = kb * 32 + l31;                   // this lane's key inside the 128-key block
+    const int wave_k_lo = n0 + kb * 32, wave_k_hi = wave_k_lo + 31;
 
-    uint32_t st_goff_q[CPT], st_goff_do[CPT], st_loff[CPT];
+    // ---- LDS-DMA tables: a tile is 1 KiB pieces (64 lanes x 16 B, lane-linear in LDS, swizzle on
+    // the source offset); wave w moves pieces [w*PPW, (w+1)*PPW) ------------------------------------
+    constexpr int PPW_KV = (kKvBlockN * SLOTS / 64) / 8;  // pieces per wave: K/V tile (4 for d=128)
+    constexpr int PPW_Q = (kKvBlockM * SLOTS / 64) / 8;   //                  Q/dO tile (2 for d=128)
+    auto piece_src = [&](int piece, uint32_t rowb) {       // global byte offset of this lane's chunk of `piece`
+        const int chunk = piece * 64 + lane, row = chunk / SLOTS, phys = chunk % SLOTS;
+        return (uint32_t)row * rowb + lds_tile_logical_slot<D>(row, phys) * 16;
+    };
+    const uint32_t lds0 = lds_addr(smem);
+    uint32_t q_src[PPW_Q], do_src[PPW_Q];                  // per-lane source offsets of this wave's Q/dO pieces
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        const int chunk = tid + c * kKvThreads, row = chunk / SLOTS, slot = chunk % SLOTS;
-        st_goff_q[c] = row * q_rowb + slot * 16;
-        st_goff_do[c] = row * do_rowb + slot * 16;
-        st_loff[c] = lds_tile_off<D>(row, slot);
+    for (int i = 0; i < PPW_Q; ++i) {
+        q_src[i] = piece_src(wave * PPW_Q + i, q_rowb);
+        do_src[i] = piece_src(wave * PPW_Q + i, do_rowb);
     }
+
+    // rows read as MFMA operands with 8 contiguous d per lane (row reads): row l31 (+32*block), slot 2*ks+hi
     uint32_t row_rd[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) row_rd[ks] = lds_tile_off<D>(l31, 2 * ks + hi);
@@ -357,14 +379,6 @@ __global__ __launch_bounds__(kKvThreads, 1) void fa_bwd_dkdv_kernel(const BwdKer
             for (int db = 0; db < DB; ++db)
                 tr_rd[sec][db] = lds_tile_off<D>(4 * hi + 8 * sec + (L >> 2), 4 * db + 2 * g + ((L & 3) >> 1)) + 8 * (L & 1);
     }
-
-    // B operands held for the whole loop: K^T and V^T fragments of this lane's key
-    u32x4 kf[KS], vf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = buf_load16(k_rs, (uint32_t)key_row * k_rowb + (2 * ks + hi) * 16);
-        vf[ks] = buf_load16(v_rs, (uint32_t)key_row * v_rowb + (2 * ks + hi) * 16);
-    }
     const float c = p.scale_log2e;
 
     f32x16 dkacc[DB], dvacc[DB];
@@ -373,26 +387,26 @@ __global__ __launch_bounds__(kKvThreads, 1) void fa_bwd_dkdv_kernel(const BwdKer
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[db][r] = 0.f; dvacc[db][r] = 0.f; }
 
-    // iteration -> (query head, q tile) and the global pieces needed to stage it
+    // iteration -> (query head, first row of the q tile)
     auto tile_coords = [&](int it, int& hq, int& m0) {
         const int g = it / tiles_per_head;
         hq = head_k * p.h_ratio + g;
         m0 = (qt_begin + (it - g * tiles_per_head)) * kKvBlockM;
     };
-    u32x4 st_q[CPT], st_do[CPT];
     float st_stat = 0.f;
-    auto issue_loads = [&](int it) {
+    auto issue_tile = [&](int it, int buf) {               // Q/dO tile `it` -> ring slot buf (DMA) ; stats -> register
         int hq, m0;
         tile_coords(it, hq, m0);
         const int rows = min(kKvBlockM, sq - m0);
         const T* qb = uniform_ptr((const T*)p.q_ptr + q_boff + (q_row0 + m0) * p.q.row + (int64_t)hq * p.q.head);
         const T* dob = uniform_ptr((const T*)p.do_ptr + do_boff + (q_row0 + m0) * p.dout.row + (int64_t)hq * p.dout.head);
-        const rsrc_t q_rs = make_rsrc(qb, (uint32_t)(rows - 1) * q_rowb + ROWB);
-        const rsrc_t do_rs = make_rsrc(dob, (uint32_t)(rows - 1) * do_rowb + ROWB);
+        const srd_t q_srd = make_srd(qb, (uint32_t)(rows - 1) * q_rowb + ROWB);
+        const srd_t do_srd = make_srd(dob, (uint32_t)(rows - 1) * do_rowb + ROWB);
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            st_q[i] = buf_load16(q_rs, st_goff_q[i]);
-            st_do[i] = buf_load16(do_rs, st_goff_do[i]);
+        for (int i = 0; i < PPW_Q; ++i) {
+            const int piece = wave * PPW_Q + i;
+            dma16_to_lds_hidden(q_srd, q_src[i], lds0 + OFF_Q + buf * TILEB + piece * 1024);
+            dma16_to_lds_hidden(do_srd, do_src[i], lds0 + OFF_DO + buf * TILEB + piece * 1024);
         }
         // threads 0..63 fetch LSE (scaled to log2 units), 64..127 fetch D; rows past the end -> 0
         const int64_t so = ((int64_t)batch * p.h + hq) * p.lse_row_stride + m0;
@@ -402,116 +416,138 @@ __global__ __launch_bounds__(kKvThreads, 1) void fa_bwd_dkdv_kernel(const BwdKer
             if (r < rows) st_stat = (tid < kKvBlockM) ? p.lse_ptr[so + r] * kLog2e : p.dsum_ptr[so + r];
         }
     };
-    auto land_loads = [&](int buf) {
-        FA_LDS char* qd = smem + buf * TILEB;
-        FA_LDS char* dd = smem + 2 * TILEB + buf * TILEB;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            lds_write16(qd, st_loff[i], st_q[i]);
-            lds_write16(dd, st_loff[i], st_do[i]);
-        }
+    auto land_stats = [&](int buf) {
         if (tid < 2 * kKvBlockM) *(FA_LDS float*)(stat + buf * STATB + tid * 4) = st_stat;
     };
 
-    if (n_iters > 0) {
-        issue_loads(0);
-        land_loads(0);
+    // ---- prologue: this workgroup's K and V tiles + the first Q/dO tile ---------------------------
+#pragma unroll
+    for (int i = 0; i < PPW_KV; ++i) {
+        const int piece = wave * PPW_KV + i;
+        dma16_to_lds_hidden(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
+        dma16_to_lds_hidden(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
     }
+    if (n_iters > 0) {
+        issue_tile(0, 0);
+        land_stats(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     for (int it = 0; it < n_iters; ++it) {
         int hq, m0;
         tile_coords(it, hq, m0);
         const int buf = it & 1;
-        FA_LDS char* qbuf = smem + buf * TILEB;
-        FA_LDS char* dobuf = smem + 2 * TILEB + buf * TILEB;
+        FA_LDS char* qbuf = smem + OFF_Q + buf * TILEB;
+        FA_LDS char* dobuf = smem + OFF_DO + buf * TILEB;
         FA_LDS char* sbuf = stat + buf * STATB;
-        __syncthreads();
         const bool more = (it + 1 < n_iters);
-        if (more) issue_loads(it + 1);
+        if (more) issue_tile(it + 1, buf ^ 1);             // ring slot buf^1 was last read in iteration it-1
 
-        // wave-level causal skip: all 64 rows of the tile are above the diagonal for all 32 keys
-        const bool wave_active = !CAUSAL || (wave_k_lo <= m0 + kKvBlockM - 1 + delta);
+        // wave-level causal skip: all 32 rows of this wave's half are above the diagonal for all its 32 keys
+        const int mh = m0 + 32 * qh;                       // first query row of this wave's half
+        const bool wave_active = !CAUSAL || (wave_k_lo <= mh + 31 + delta);
         if (wave_active) {
-            const bool need_mask = CAUSAL && (wave_k_hi > m0 + delta);
+            const bool need_mask = CAUSAL && (wave_k_hi > mh + delta);
             const int key = n0 + key_row;
+            f32x16 sacc, dpacc;
 #pragma unroll
-            for (int bi = 0; bi < 2; ++bi) {           // two 32-row halves of the Q tile
-                f32x16 sacc, dpacc;
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 qa = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
+                const u32x4 kf = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
+                sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
+            }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const u32x4 qa = lds_read16(qbuf, row_rd[ks] + bi * 32 * ROWB);
-                    sacc = LP<T>::mfma(qa, kf[ks], sacc);           // S = Q K^T  (rows = queries, lane = key)
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 da = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
+                const u32x4 vf = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
+                dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
+            }
+            f32x16 pacc;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // registers 4*g4.. = query rows 32*qh + 8*g4 + 4*hi + {0..3} of the tile
+                const int rbase = 32 * qh + 8 * g4 + 4 * hi;
+                const f32x4 l4 = *(const FA_LDS f32x4*)(sbuf + rbase * 4);
+                const f32x4 d4 = *(const FA_LDS f32x4*)(sbuf + kKvBlockM * 4 + rbase * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -l4[e]));
+                    if (need_mask) pv = (key <= m0 + rbase + e + delta) ? pv : 0.f;
+                    pacc[r] = pv;
+                    sacc[r] = pv * (dpacc[r] - d4[e]);
                 }
+            }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const u32x4 da = lds_read16(dobuf, row_rd[ks] + bi * 32 * ROWB);
-                    dpacc = LP<T>::mfma(da, vf[ks], dpacc);         // dP = dO V^T
-                }
-                f32x16 pacc;
+            for (int half = 0; half < 2; ++half) {
+                const u32x4 pf = pack_c_half<T>(pacc, half);        // P rounded (flash_bwd_kernel.h:1359)
+                const u32x4 dsf = pack_c_half<T>(sacc, half);       // dS rounded (:1360)
+                const int ts = 2 * qh + half;                       // 16-row k-slice of the 64-row tile
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    // registers 4*g4.. = query rows 32*bi + 8*g4 + 4*hi + {0..3}
-                    const int rbase = 32 * bi + 8 * g4 + 4 * hi;
-                    const f32x4 l4 = *(const FA_LDS f32x4*)(sbuf + rbase * 4);
-                    const f32x4 d4 = *(const FA_LDS f32x4*)(sbuf + kKvBlockM * 4 + rbase * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g4 + e;
-                        float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -l4[e]));
-                        if (need_mask) pv = (key <= m0 + rbase + e + delta) ? pv : 0.f;
-                        pacc[r] = pv;
-                        sacc[r] = pv * (dpacc[r] - d4[e]);
-                    }
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const u32x4 pf = pack_c_half<T>(pacc, half);    // P rounded (flash_bwd_kernel.h:1359)
-                    const u32x4 dsf = pack_c_half<T>(sacc, half);   // dS rounded (:1360)
-                    const int ts = 2 * bi + half;
-#pragma unroll
-                    for (int db = 0; db < DB; ++db) {
-                        const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
-                        const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
-                        const u32x4 dot = {a0.x, a0.y, a1.x, a1.y};
-                        dvacc[db] = LP<T>::mfma(dot, pf, dvacc[db]);       // dV^T += dO^T P
-                        const u32x2 b0 = lds_read_tr8(qbuf, tr_rd[0][db] + ts * 16 * ROWB);
-                        const u32x2 b1 = lds_read_tr8(qbuf, tr_rd[1][db] + ts * 16 * ROWB);
-                        const u32x4 qt = {b0.x, b0.y, b1.x, b1.y};
-                        dkacc[db] = LP<T>::mfma(qt, dsf, dkacc[db]);       // dK^T += Q^T dS
-                    }
+                for (int db = 0; db < DB; ++db) {
+                    const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
+                    const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
+                    const u32x4 dot = {a0.x, a0.y, a1.x, a1.y};
+                    LP<T>::mfma_agpr(dvacc[db], dot, pf);           // dV^T += dO^T P    (AGPR accumulator)
+                    const u32x2 b0 = lds_read_tr8(qbuf, tr_rd[0][db] + ts * 16 * ROWB);
+                    const u32x2 b1 = lds_read_tr8(qbuf, tr_rd[1][db] + ts * 16 * ROWB);
+                    const u32x4 qt = {b0.x, b0.y, b1.x, b1.y};
+                    LP<T>::mfma_agpr(dkacc[db], qt, dsf);           // dK^T += Q^T dS    (AGPR accumulator)
                 }
             }
         }
-        if (more) land_loads(buf ^ 1);
+        if (more) land_stats(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces have landed
+        __syncthreads();
     }
 
-    // epilogue: dK *= scale (flash_bwd_kernel.h:1652-1654); round; stage; whole-row stores
-    __syncthreads();
-    FA_LDS char* dk_t = smem;
-    FA_LDS char* dv_t = smem + kKvBlockN * ROWB;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            u32x2 w;
-            w.x = LP<T>::pack2(dkacc[db][4 * g4 + 0] * p.scale, dkacc[db][4 * g4 + 1] * p.scale);
-            w.y = LP<T>::pack2(dkacc[db][4 * g4 + 2] * p.scale, dkacc[db][4 * g4 + 3] * p.scale);
-            lds_write8(dk_t, lds_tile_off<D>(key_row, 4 * db + g4) + 8 * hi, w);
-            u32x2 x;
-            x.x = LP<T>::pack2(dvacc[db][4 * g4 + 0], dvacc[db][4 * g4 + 1]);
-            x.y = LP<T>::pack2(dvacc[db][4 * g4 + 2], dvacc[db][4 * g4 + 3]);
-            lds_write8(dv_t, lds_tile_off<D>(key_row, 4 * db + g4) + 8 * hi, x);
-        }
-    __syncthreads();
+    // ---- epilogue -------------------------------------------------------------------------------------
+    // (the loop's last barrier has passed: K/V tiles, rings and stats are dead, LDS is scratch)
+    // 1) the qh = 1 waves hand their partial sums to their qh = 0 partner through LDS (fp32,
+    //    [key block][register][lane], conflict-free); 2) the partner adds, applies the softmax
+    //    scale to dK (flash_bwd_kernel.h:1652-1654), rounds and writes the staged 128-key tile;
+    //    3) all threads store whole rows.  dK and dV take turns in the same scratch.
+    constexpr int XR = DB * 16;                                                // accumulator registers per lane and tensor
+    FA_LDS float* xch = (FA_LDS float*)smem;                                   // 4 key blocks x XR x 64 lanes floats (64 KiB at d=128)
+    FA_LDS char* out_t = smem + 4 * XR * 64 * 4;                               // staged output tile (32 KiB at d=128)
+    static_assert(4 * XR * 64 * 4 + kKvBlockN * ROWB <= OFF_STAT, "epilogue scratch must fit");
     constexpr int O_CHUNKS = (kKvBlockN * SLOTS) / kKvThreads;
+    auto reduce_and_store = [&](f32x16 (&acc)[DB], float mult, rsrc_t rs, uint32_t rowb) {
+        if (qh == 1) {
 #pragma unroll
-    for (int i = 0; i < O_CHUNKS; ++i) {
-        const int chunk = tid + i * kKvThreads, row = chunk / SLOTS, slot = chunk % SLOTS;
-        buf_store16(dk_rs, (uint32_t)row * dk_rowb + slot * 16, lds_read16(dk_t, lds_tile_off<D>(row, slot)));
-        buf_store16(dv_rs, (uint32_t)row * dv_rowb + slot * 16, lds_read16(dv_t, lds_tile_off<D>(row, slot)));
-    }
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(kb * XR + db * 16 + r) * 64 + lane] = acc[db][r];
+        }
+        __syncthreads();
+        if (qh == 0) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v4[e] = (acc[db][4 * g4 + e] + xch[(kb * XR + db * 16 + 4 * g4 + e) * 64 + lane]) * mult;
+                    u32x2 w;
+                    w.x = LP<T>::pack2(v4[0], v4[1]);
+                    w.y = LP<T>::pack2(v4[2], v4[3]);
+                    lds_write8(out_t, lds_tile_off<D>(key_row, 4 * db + g4) + 8 * hi, w);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < O_CHUNKS; ++i) {
+            const int chunk = tid + i * kKvThreads, row = chunk / SLOTS, slot = chunk % SLOTS;
+            buf_store16(rs, (uint32_t)row * rowb + slot * 16, lds_read16(out_t, lds_tile_off<D>(row, slot)));
+        }
+        __syncthreads();                                                       // scratch is reused by the next tensor
+    };
+    reduce_and_store(dkacc, p.scale, dk_rs, dk_rowb);
+    reduce_and_store(dvacc, 1.0f, dv_rs, dv_rowb);
 }
 
 // ---------------------------------------------------------------------------------------------

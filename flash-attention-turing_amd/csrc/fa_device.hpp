@@ -48,6 +48,15 @@ struct LP<_Float16> {
     static FA_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
+    // Accumulate into an AGPR-resident tile (inline asm: "+a").  For kernels whose long-lived
+    // accumulators exceed what fits next to the working set in the 256 architectural VGPRs: built
+    // with -amdgpu-mfma-vgpr-form every BUILTIN mfma keeps its result in VGPRs (where the softmax
+    // VALU can use it directly) while these accumulators, which only MFMAs touch until the
+    // epilogue, live in the accumulator half of the register file -- no v_accvgpr shuttling.
+    // s_nop 1: a/b may have just been written by VALU (v_cvt_pk) -> MFMA source hazard.
+    static FA_DEV void mfma_agpr(f32x16& acc, u32x4 a, u32x4 b) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
     // round-to-nearest-even pack (v_cvt_pk_f16_f32): the reference rounds P/dS/O with
     // cutlass NumericArrayConverter (utils.h:19-27), which is RN as well.
     static FA_DEV uint32_t pack2(float lo, float hi) {
@@ -61,6 +70,9 @@ template <>
 struct LP<__bf16> {
     static FA_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static FA_DEV void mfma_agpr(f32x16& acc, u32x4 a, u32x4 b) {
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     }
     static FA_DEV uint32_t pack2(float lo, float hi) {
         f32x2 x = {lo, hi};
