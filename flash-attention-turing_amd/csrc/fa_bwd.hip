@@ -77,7 +77,6 @@ template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
     constexpr int TILEB = kDqBlockN * ROWB;
-    constexpr int CPT = (kDqBlockN * SLOTS) / kDqThreads;
     __shared__ __attribute__((aligned(16))) char smem_raw[(4 * TILEB > kDqBlockM * ROWB) ? 4 * TILEB : kDqBlockM * ROWB];
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
@@ -117,8 +116,8 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
     const rsrc_t q_rs = make_rsrc(q_base, (uint32_t)(rows_here - 1) * q_rowb + ROWB);
     const rsrc_t do_rs = make_rsrc(do_base, (uint32_t)(rows_here - 1) * do_rowb + ROWB);
     const rsrc_t dq_rs = make_rsrc(dq_base, (uint32_t)(rows_here - 1) * dq_rowb + ROWB);
-    const rsrc_t k_rs = make_rsrc(k_base, sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
-    const rsrc_t v_rs = make_rsrc(v_base, sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
+    const srd_t k_srd = make_srd(k_base, sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
+    const srd_t v_srd = make_srd(v_base, sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
 
     int n_tiles = (sk + kDqBlockN - 1) / kDqBlockN;
     if (CAUSAL) {
@@ -129,14 +128,26 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
     const int q_row = wave * 32 + l31;
     const int wave_q_lo = m0 + wave * 32, wave_q_hi = wave_q_lo + 31;
 
-    uint32_t st_goff_k[CPT], st_goff_v[CPT], st_loff[CPT];
+    // LDS-DMA staging (hand-issued, see fa_device.hpp:dma16_to_lds_hidden): wave w moves the DPW
+    // 1-KiB pieces [w*DPW, (w+1)*DPW) of every K and V tile; swizzle applied to the source offset.
+    constexpr int DPW = SLOTS / 8;
+    uint32_t dma_goff_k[DPW], dma_goff_v[DPW];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        const int chunk = tid + c * kDqThreads, row = chunk / SLOTS, slot = chunk % SLOTS;
-        st_goff_k[c] = row * k_rowb + slot * 16;
-        st_goff_v[c] = row * v_rowb + slot * 16;
-        st_loff[c] = lds_tile_off<D>(row, slot);
+    for (int i = 0; i < DPW; ++i) {
+        const int chunk = (wave * DPW + i) * 64 + lane, row = chunk / SLOTS, phys = chunk % SLOTS;
+        const int slot = lds_tile_logical_slot<D>(row, phys);
+        dma_goff_k[i] = row * k_rowb + slot * 16;
+        dma_goff_v[i] = row * v_rowb + slot * 16;
     }
+    const uint32_t lds_k0 = lds_addr(smem) + (uint32_t)wave * DPW * 1024;
+    const uint32_t lds_v0 = lds_k0 + 2 * TILEB;
+    auto dma_tiles = [&](int t, int buf) {                 // K(t), V(t) -> LDS buffers `buf`
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            dma16_to_lds_hidden(k_srd, (uint32_t)(t * kDqBlockN) * k_rowb + dma_goff_k[i], lds_k0 + buf * TILEB + i * 1024);
+            dma16_to_lds_hidden(v_srd, (uint32_t)(t * kDqBlockN) * v_rowb + dma_goff_v[i], lds_v0 + buf * TILEB + i * 1024);
+        }
+    };
     uint32_t row_rd[KS];       // row reads of K (for S^T) and V (for dP^T): same (row, slot) pattern
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) row_rd[ks] = lds_tile_off<D>(l31, 2 * ks + hi);
@@ -170,34 +181,20 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[db][r] = 0.f;
 
-    u32x4 st_k[CPT], st_v[CPT];
-    if (n_tiles > 0) {
+    if (n_tiles > 0) dma_tiles(0, 0);
+    // the Q / dO / LSE / D loads above are compiler-visible: force them home so the hand-counted
+    // vmcnt(0) below also covers the DMA pieces
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            st_k[i] = buf_load16(k_rs, st_goff_k[i]);
-            st_v[i] = buf_load16(v_rs, st_goff_v[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            lds_write16(smem, st_loff[i], st_k[i]);
-            lds_write16(smem + 2 * TILEB, st_loff[i], st_v[i]);
-        }
-    }
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
+    asm volatile("" : "+v"(lse2), "+v"(dsum));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     for (int t = 0; t < n_tiles; ++t) {
         const int n0 = t * kDqBlockN;
         FA_LDS char* kbuf = smem + (t & 1) * TILEB;
         FA_LDS char* vbuf = smem + 2 * TILEB + (t & 1) * TILEB;
-        __syncthreads();
-        const bool more = (t + 1 < n_tiles);
-        if (more) {
-            const uint32_t gk = (uint32_t)(n0 + kDqBlockN) * k_rowb, gv = (uint32_t)(n0 + kDqBlockN) * v_rowb;
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                st_k[i] = buf_load16(k_rs, gk + st_goff_k[i]);
-                st_v[i] = buf_load16(v_rs, gv + st_goff_v[i]);
-            }
-        }
+        __syncthreads();      // tile t is in LDS (every wave waited for its pieces); buffer (t+1)&1 is free again
+        if (t + 1 < n_tiles) dma_tiles(t + 1, (t + 1) & 1);
         const bool wave_active = !CAUSAL || (n0 <= wave_q_hi + delta);
         if (wave_active) {
             const bool need_mask = (n0 + kDqBlockN > sk) || (CAUSAL && (n0 + kDqBlockN - 1 > wave_q_lo + delta));
@@ -242,15 +239,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
                 }
             }
         }
-        if (more) {
-            FA_LDS char* kn = smem + ((t + 1) & 1) * TILEB;
-            FA_LDS char* vn = smem + 2 * TILEB + ((t + 1) & 1) * TILEB;
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                lds_write16(kn, st_loff[i], st_k[i]);
-                lds_write16(vn, st_loff[i], st_v[i]);
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
     }
 
     // epilogue: dQ *= scale (flash_bwd_kernel.h:765), round, stage through LDS, whole-row stores

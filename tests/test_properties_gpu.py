@@ -170,3 +170,67 @@ def test_kernels_run_on_the_current_stream(gpu):
         out, _ = F.fwd(q, k, v, False)
     side.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_64bit_offsets_at_config5_total_size(gpu):
+    """BASELINE configs[4] total size on ONE GPU: b=32, s=16384, h=32, d=128 is exactly 2^31 elements per
+    tensor -- the reference's int32 offsets (block_info.h:15-21) overflow here.  The last batch entries of
+    the big call must be bit-identical to computing them on their own."""
+    import flash_attn_turing as F
+
+    b, s, h, d = 32, 16384, 32, 128
+    gen = torch.Generator(device=gpu).manual_seed(50)
+    q = torch.randn(b, s, h, d, device=gpu, dtype=torch.float16, generator=gen)
+    k = torch.randn(b, s, h, d, device=gpu, dtype=torch.float16, generator=gen)
+    v = torch.randn(b, s, h, d, device=gpu, dtype=torch.float16, generator=gen)
+    assert q.numel() == 2 ** 31
+    o, lse = F.fwd(q, k, v, True)
+    for bi in (0, 15, 16, 31):                      # element offsets 0, just below / at 2^30, and near 2^31
+        o1, l1 = F.fwd(q[bi:bi + 1], k[bi:bi + 1], v[bi:bi + 1], True)
+        assert torch.equal(o[bi:bi + 1], o1) and torch.equal(lse[bi:bi + 1], l1), f"batch {bi}"
+    del o, lse
+    torch.cuda.empty_cache()
+
+
+def test_empty_and_degenerate_shapes(gpu):
+    import flash_attn_turing as F
+
+    h = lambda *s: torch.randn(*s, device=gpu, dtype=torch.float16)
+    # no keys at all: every row is dead -> O = 0, LSE = 0; gradients are zero
+    q, k, v = h(2, 5, 4, 128), h(2, 0, 2, 128), h(2, 0, 2, 128)
+    o, lse = F.fwd(q, k, v, False)
+    assert o.shape == q.shape and (o == 0).all() and (lse == 0).all()
+    dq, dk, dv = F.bwd(q, k, v, o, lse, torch.ones_like(q), False)
+    assert (dq == 0).all() and dk.shape == k.shape and dv.shape == v.shape
+    # no queries
+    q0 = h(2, 0, 4, 128)
+    k1, v1 = h(2, 7, 2, 128), h(2, 7, 2, 128)
+    o0, l0 = F.fwd(q0, k1, v1, True)
+    assert o0.shape == q0.shape and l0.shape == (2, 4, 0)
+    dq0, dk0, dv0 = F.bwd(q0, k1, v1, o0, l0, q0.clone(), True)
+    assert dq0.numel() == 0 and (dk0 == 0).all() and (dv0 == 0).all()
+    # varlen with an empty sequence in the middle
+    cu_q = torch.tensor([0, 3, 3, 10], device=gpu, dtype=torch.int32)
+    cu_k = torch.tensor([0, 4, 9, 9], device=gpu, dtype=torch.int32)     # last sequence has queries but no keys
+    qp, kp, vp = h(10, 2, 64), h(9, 2, 64), h(9, 2, 64)
+    o, lse = F.varlen_fwd(qp, kp, vp, cu_q, cu_k, 7, 5, True)
+    assert torch.isfinite(o).all() and (o[3:] == 0).all() and (lse[2] == 0).all()
+    dq, dk, dv = F.varlen_bwd(qp, kp, vp, o, lse, torch.ones_like(qp), cu_q, cu_k, 7, 5, True)
+    assert torch.isfinite(dq).all() and (dq[3:] == 0).all() and (dk[4:] == 0).all() and (dv[4:] == 0).all()
+
+
+def test_large_magnitude_inputs_stay_finite(gpu):
+    """scores of +-several hundred (raw q.k up to ~5000): exp2 arguments far outside fp16 range must not
+    produce inf/NaN; the result must still match fp32 math."""
+    import flash_attn_turing as F
+
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    q = (torch.randn(1, 384, 2, 128, generator=gen) * 6).to(gpu, torch.float16)
+    k = (torch.randn(1, 640, 2, 128, generator=gen) * 6).to(gpu, torch.float16)
+    v = torch.randn(1, 640, 2, 128, generator=gen).to(gpu, torch.float16)
+    for causal in (False, True):
+        o, lse = F.fwd(q, k, v, causal)
+        o_r, lse_r = U.torch_attention_ref(q, k, v, None, causal)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        U.assert_close(o.float().cpu().numpy(), o_r.cpu().numpy(), "fp16", "O large", scale=2.0)
+        assert ((lse - lse_r).abs() / lse_r.abs().clamp_min(1.0)).max().item() <= 1e-4
