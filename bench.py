@@ -318,6 +318,16 @@ def main():
             f(); sync()
             ms = event_time_ms(torch, f, 20 if ss <= 4096 else 8)
             sweep[str(ss)] = {"ms": ms, "tflops": fwd_flops(4, ss, ss, 32, 128, False) / ms / 1e9}
+            # the reference's headline comparison (README.md:16 "around 2x faster than PyTorch attention"), on THIS GPU:
+            # PyTorch-ROCm's own fused SDPA on the same tensors ((b,h,s,d) strided views, no copy)
+            try:
+                qt, kt, vt = (et[n].permute(0, 2, 1, 3) for n in ("q", "k", "v"))
+                g = lambda: torch.nn.functional.scaled_dot_product_attention(qt, kt, vt)
+                g(); sync()
+                sms = event_time_ms(torch, g, 20 if ss <= 4096 else 8)
+                sweep[str(ss)].update({"torch_sdpa_ms": sms, "speedup_vs_torch_sdpa": sms / ms})
+            except Exception as exc:  # noqa: BLE001
+                sweep[str(ss)]["torch_sdpa_error"] = str(exc)[:80]
             del et
         extra["sweep_b4_h32_d128_fp16_noncausal"] = sweep
 
