@@ -35,10 +35,6 @@ constexpr float kLn2 = 0.6931471805599453f;
 // that have not seen a visible key yet (SURVEY.md Appendix A dead-row convention).
 constexpr float kNegBig = -1.0e30f;
 
-struct Strides {
-    int64_t batch, row, head;
-};
-
 // ---- low-precision element traits ----------------------------------------------------------
 template <typename T>
 struct LP;
