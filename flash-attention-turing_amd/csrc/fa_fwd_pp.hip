@@ -197,6 +197,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         }
+        // (scalar v_fma / v_add on purpose: the float2 form -- v_pk_fma_f32 / v_pk_add_f32, half the
+        // instructions -- measured 5 % SLOWER next to the partner wave's MFMAs, tools/fwd_ab.py)
         const float mc = m_run * c;
         float psum = 0.f;
 #pragma unroll
