@@ -78,7 +78,7 @@ class Dist:
     def barrier(self, device=None):
         if self.enabled:
             if self.backend == "nccl":
-                self.dist.barrier(device_ids=[self.local_rank])
+                self.dist.barrier(device_ids=[device.index if device is not None else self.local_rank])
             else:
                 self.dist.barrier()
 
@@ -262,7 +262,9 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path is HIP-only, there is no CPU fallback")
     from flash_attn_turing import capi   # fails loudly if the HIP build is missing
 
-    device = torch.device("cuda", dist.local_rank)
+    # one rank per GPU; the modulo only matters when the harness itself is exercised with more ranks
+    # than devices (e.g. --backend gloo with 2 ranks on a 1-GPU box)
+    device = torch.device("cuda", dist.local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     b, s, h, hk, d, dtype, causal, backward = WORKLOADS[args.workload]
     t = make_inputs(torch, device, b, s, h, hk, d, dtype, 1234 + dist.rank, backward)
