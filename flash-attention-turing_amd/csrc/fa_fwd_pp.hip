@@ -160,10 +160,24 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
     // barrier that ends the phase, by which time (the partner's matrix phase is longer than this
     // wave's softmax) the data has arrived.  Previous tenants K(u-1) / V(u-2) were last read in
     // M(u-1) of the other group, at least one barrier ago.
+    // The DMA issue cost (~60-100 cycles per 1-KiB piece) is split between the two phases: the V
+    // pieces are issued here, at the start of S(u) (compiler-visible builtin, see above); the K
+    // pieces are issued by hand at the very END of M(u), after the phase's last LDS read, where the
+    // wave would otherwise just wait for its partner at the barrier -- hidden from hipcc so that the
+    // barrier ending the matrix phase does not drain them; they are retired by the explicit
+    // vmcnt(0) at the end of S(u).  K(u+2)'s slot tenant K(u-1) was last read in M(u-1) of the other
+    // group, one barrier before the earliest issue.
+    const srd_t k_srd = make_srd(k_base, sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
+    const uint32_t lds_k0 = lds_addr(kring) + dma_loff;
+    auto issue_dma_k = [&](int u) {
+        if (u + 2 < n_tiles) {
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+                dma16_to_lds_hidden(k_srd, (uint32_t)((u + 2) * kFwdBlockN) * k_rowb + dma_goff_k[i], lds_k0 + ring_um1 * TILEB + i * 1024);
+        }
+    };
     auto issue_dma = [&](int u) {
-        const int n0 = u * kFwdBlockN;
-        if (u + 2 < n_tiles) dma_tile(k_rs, dma_goff_k, (uint32_t)(n0 + 2 * kFwdBlockN) * k_rowb, kring + ring_um1 * TILEB);
-        if (u + 1 < n_tiles) dma_tile(v_rs, dma_goff_v, (uint32_t)(n0 + kFwdBlockN) * v_rowb, vring + ring_up1 * TILEB);
+        if (u + 1 < n_tiles) dma_tile(v_rs, dma_goff_v, (uint32_t)((u + 1) * kFwdBlockN) * v_rowb, vring + ring_up1 * TILEB);
     };
     auto softmax_step = [&](int u, auto masked) {
         const int n0 = u * kFwdBlockN;
@@ -239,6 +253,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
         if (prev_active) pv_step();
         if (active) qk_step();
         if (!in_range) return;                        // drain iteration: only the pending PV
+        issue_dma_k(u);
         __syncthreads();
         issue_dma(u);
         if (active) softmax_step(u, yes{});
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
     int u = 0;
     if (n_main > 0) {                                 // pipeline fill: tile 0 has no pending PV
         qk_step();
+        issue_dma_k(0);
         __syncthreads();
         issue_dma(0);
         softmax_step(0, no{});
@@ -259,6 +275,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
         for (u = 1; u < n_main; ++u) {                // steady state
             pv_step();
             qk_step();
+            issue_dma_k(u);
             __syncthreads();
             issue_dma(u);
             softmax_step(u, no{});
