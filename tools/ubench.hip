@@ -16,10 +16,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 enum { T_EXP, T_FMA, T_ADD, T_MAX3, T_CVT, T_PKFMA, T_PKMUL, T_PKADD, T_EXPH, T_LDEXP, T_LSHLADD, T_MIX_EXP_FMA, T_MFMA, T_LOG, T_RCP,
-       T_MFMA16, T_STREAM4, T_STREAM5, T_STREAM6, T_NUM };
+       T_MFMA16, T_STREAM4, T_STREAM5, T_STREAM6, T_MFMA_NOP20, T_MFMA_NOP26, T_MFMA_SLEEP, T_MN3, T_MN4, T_MN5, T_MN6, T_MN7, T_NUM };
 static const char* kNames[] = {"v_exp_f32", "v_fma_f32", "v_add_f32", "v_max3_f32", "v_cvt_pk_f16_f32", "v_pk_fma_f32", "v_pk_mul_f32",
                                "v_pk_add_f32", "v_exp_f16", "v_ldexp_f32", "v_lshl_add_u32", "8 exp + 8 fma interleaved", "v_mfma_32x32x16_f16",
-                               "v_log_f32", "v_rcp_f32", "v_mfma_16x16x32_f16", "stream 1 mfma : 4 valu (1 exp)", "stream 1 mfma : 5 valu (1 exp)", "stream 1 mfma : 6 valu (1 exp)"};
+                               "v_log_f32", "v_rcp_f32", "v_mfma_16x16x32_f16", "stream 1 mfma : 4 valu (1 exp)", "stream 1 mfma : 5 valu (1 exp)", "stream 1 mfma : 6 valu (1 exp)", "mfma + s_nop(20)", "mfma + s_nop(26)", "mfma + s_sleep 0", "mn3", "mn4", "mn5", "mn6", "mn7"};
 
 template <int TEST>
 __device__ __forceinline__ void body(float (&r)[16], f32x2 (&pk)[16], f32x16& acc, f32x16& acc2, f16x8 a, f16x8 b) {
@@ -98,6 +98,29 @@ __device__ __forceinline__ void body(float (&r)[16], f32x2 (&pk)[16], f32x16& ac
         if (TEST == T_STREAM6) asm volatile("v_add_f32 %0, %0, %0" : "+v"(r[(i + 11) & 15]));
         REP16(X)
 #undef X
+    } else if constexpr (TEST == T_MFMA_NOP20 || TEST == T_MFMA_NOP26 || TEST == T_MFMA_SLEEP) {
+        // does an MFMA wave that does NOT ask for the VALU/MFMA issue port early leave it to its SIMD partner?
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+            if (TEST == T_MFMA_NOP20) asm volatile("s_nop 15\n\ts_nop 3");
+            else if (TEST == T_MFMA_NOP26) asm volatile("s_nop 15\n\ts_nop 9");
+            else asm volatile("s_sleep 0");
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0);
+            if (TEST == T_MFMA_NOP20) asm volatile("s_nop 15\n\ts_nop 3");
+            else if (TEST == T_MFMA_NOP26) asm volatile("s_nop 15\n\ts_nop 9");
+            else asm volatile("s_sleep 0");
+        }
+    } else if constexpr (TEST >= T_MN3 && TEST <= T_MN7) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+            if (TEST == T_MN3) asm volatile("s_nop 3"); else if (TEST == T_MN4) asm volatile("s_nop 4"); else if (TEST == T_MN5) asm volatile("s_nop 5");
+            else if (TEST == T_MN6) asm volatile("s_nop 6"); else asm volatile("s_nop 7");
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc2, 0, 0, 0);
+            if (TEST == T_MN3) asm volatile("s_nop 3"); else if (TEST == T_MN4) asm volatile("s_nop 4"); else if (TEST == T_MN5) asm volatile("s_nop 5");
+            else if (TEST == T_MN6) asm volatile("s_nop 6"); else asm volatile("s_nop 7");
+        }
     } else if constexpr (TEST == T_MFMA16) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4 c0 = {acc[0], acc[1], acc[2], acc[3]}, c1 = {acc[4], acc[5], acc[6], acc[7]};
@@ -188,6 +211,20 @@ int main() {
     run<T_STREAM4, T_STREAM4>(d, 512, "mixed 1:4 | mixed 1:4");
     run<T_STREAM5, T_STREAM5>(d, 512, "mixed 1:5 | mixed 1:5");
     run<T_STREAM6, T_STREAM6>(d, 512, "mixed 1:6 | mixed 1:6");
+    run<T_MFMA_NOP20, T_MFMA_NOP20>(d, 256, "mfma + s_nop 20 alone");
+    run<T_MFMA_NOP26, T_MFMA_NOP26>(d, 256, "mfma + s_nop 26 alone");
+    run<T_MFMA_NOP20, T_FMA>(d, 512, "mfma+nop20 | fma");
+    run<T_MFMA_NOP26, T_FMA>(d, 512, "mfma+nop26 | fma");
+    run<T_MFMA_NOP26, T_EXP>(d, 512, "mfma+nop26 | exp");
+    run<T_MFMA_NOP26, T_MIX_EXP_FMA>(d, 512, "mfma+nop26 | exp+fma");
+    run<T_MFMA_SLEEP, T_FMA>(d, 512, "mfma+sleep0 | fma");
+    run<T_MN3, T_MIX_EXP_FMA>(d, 512, "mfma+s_nop 3 | exp+fma");
+    run<T_MN4, T_MIX_EXP_FMA>(d, 512, "mfma+s_nop 4 | exp+fma");
+    run<T_MN5, T_MIX_EXP_FMA>(d, 512, "mfma+s_nop 5 | exp+fma");
+    run<T_MN6, T_MIX_EXP_FMA>(d, 512, "mfma+s_nop 6 | exp+fma");
+    run<T_MN7, T_MIX_EXP_FMA>(d, 512, "mfma+s_nop 7 | exp+fma");
+    run<T_MN5, T_MN5>(d, 256, "mfma+s_nop 5 alone");
+    run<T_MN6, T_MN6>(d, 256, "mfma+s_nop 6 alone");
     printf("== priorities (A prio, B prio) ==\n");
     run<T_MFMA, T_FMA, 0, 1>(d, 512, "mfma(p0) | fma(p1)");
     run<T_MFMA, T_FMA, 0, 3>(d, 512, "mfma(p0) | fma(p3)");
