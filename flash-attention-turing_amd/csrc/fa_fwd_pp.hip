@@ -8,6 +8,13 @@
 
 #include <type_traits>
 
+// FA_ABL: TIMING-ONLY ablations for tools/ablate_fwd.py (results are WRONG when non-zero; never shipped:
+// build.py does not define it).  bit0: no v_exp in the softmax phase; bit1: no fma/exp/row-sum at all;
+// bit2: the matrix phase reads only every other K / V fragment from LDS (half the LDS bytes per MFMA).
+#ifndef FA_ABL
+#define FA_ABL 0
+#endif
+
 namespace fa {
 
 constexpr int kFwdThreads = 512;
@@ -127,6 +134,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
 
     f32x16 sacc[2];
     u32x4 pf[4];
+#if FA_ABL & 4
+    u32x4 abl_kf = {0, 0, 0, 0}, abl_vf = {0, 0, 0, 0};
+#endif
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // u % 3, (u-1) % 3 == (u+2) % 3, (u+1) % 3
 
     // ---- phase bodies ---------------------------------------------------------------------------
@@ -136,9 +146,19 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int ts = 0; ts < 4; ++ts) {
+#if FA_ABL & 4
+                u32x4 vf;
+                if ((ts & 1) == 0) {
+                    const u32x2 a0 = lds_read_tr8(vbuf, v_rd[0][db] + ts * 16 * ROWB);
+                    const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
+                    abl_vf = u32x4{a0.x, a0.y, a1.x, a1.y};
+                }
+                vf = abl_vf;
+#else
                 const u32x2 a0 = lds_read_tr8(vbuf, v_rd[0][db] + ts * 16 * ROWB);
                 const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
                 const u32x4 vf = {a0.x, a0.y, a1.x, a1.y};
+#endif
                 oacc[db] = LP<T>::mfma(vf, pf[ts], oacc[db]);
             }
     };
@@ -150,7 +170,12 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
             for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+#if FA_ABL & 4
+                if ((ks & 1) == 0) abl_kf = lds_read16(kbuf, k_rd[ks] + bi * 32 * ROWB);
+                const u32x4 kf = abl_kf;
+#else
                 const u32x4 kf = lds_read16(kbuf, k_rd[ks] + bi * 32 * ROWB);
+#endif
                 sacc[bi] = LP<T>::mfma(kf, qf[ks], sacc[bi]);
             }
         }
@@ -219,9 +244,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKern
         for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc));
-                sacc[bi][r] = pv;
+#if FA_ABL & 2
+                const float pv = sacc[bi][r];
+#elif FA_ABL & 1
+                float pv = __builtin_fmaf(sacc[bi][r], c, -mc);   // exp -> one plain VALU op (asm: keeps hipcc from packing the fmas)
+                asm volatile("v_add_f32 %0, 0, %0" : "+v"(pv));
                 psum += pv;
+#else
+                const float pv = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc));
+                psum += pv;
+#endif
+                sacc[bi][r] = pv;
             }
         l_run += psum;
 #pragma unroll
