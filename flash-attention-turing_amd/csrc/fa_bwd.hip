@@ -16,6 +16,7 @@
 //     the dK^T / dV^T accumulators live in AGPRs;
 //   * the GQA group loop is fused into the dK/dV kernel (the reference materialises per-q-head
 //     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312).
+#include <type_traits>
 #include "fa_device.hpp"
 #include "fa_params.hpp"
 
@@ -197,8 +198,15 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
         if (t + 1 < n_tiles) dma_tiles(t + 1, (t + 1) & 1);
         const bool wave_active = !CAUSAL || (n0 <= wave_q_hi + delta);
         if (wave_active) {
+            // Masking is 2 VALU per score element (compare with an immediate + select), not 4: the key index of
+            // element (bi, r) is n0 + 32*bi + (r&3) + 8*(r>>2) + 4*hi, so everything lane- or tile-dependent
+            // (n0, hi, the causal / sk limit, and whether this tile needs a mask at all) is folded ONCE per tile
+            // into `lim_loc`; per element only the compile-time constant 32*bi + (r&3) + 8*(r>>2) is compared.
+            // (Two tile bodies behind a scalar branch remove the mask entirely from interior tiles but push the
+            // D=128 kernel from 233 to 256 VGPRs + 97 spills -- measured in the ISA, not shipped.)
             const bool need_mask = (n0 + kDqBlockN > sk) || (CAUSAL && (n0 + kDqBlockN - 1 > wave_q_lo + delta));
             const int lim = CAUSAL ? min(sk - 1, m0 + q_row + delta) : sk - 1;
+            const int lim_loc = need_mask ? lim - n0 - 4 * hi : 0x7fffffff;
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi) {           // two 32-key halves, keeps S/dP at 16+16 regs
                 f32x16 sacc, dpacc;
@@ -218,10 +226,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKerne
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -lse2));
-                    if (need_mask) {
-                        const int key = n0 + 32 * bi + c_row(r, hi);
-                        pv = key <= lim ? pv : 0.f;
-                    }
+                    pv = (32 * bi + (r & 3) + 8 * (r >> 2)) <= lim_loc ? pv : 0.f;
                     sacc[r] = pv * (dpacc[r] - dsum);
                 }
                 // dQ^T (D x 32 queries) += K^T (D x 32 keys) * dS^T (32 keys x 32 queries)
