@@ -440,10 +440,20 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv_kernel(const BwdKer
 
         // wave-level causal skip: all 32 rows of this wave's half are above the diagonal for all its 32 keys
         const int mh = m0 + 32 * qh;                       // first query row of this wave's half
-        const bool wave_active = !CAUSAL || (wave_k_lo <= mh + 31 + delta);
-        if (wave_active) {
+        // No wave-level causal skip here, on purpose.  `if (wave_active) { body }` around a body whose accumulators are
+        // inline-asm "+a" operands makes hipcc copy all 128 accumulator registers out and back every iteration (258
+        // v_accvgpr moves + 48 scratch ops in the D=128 loop, 147 moves at D=64).  A fully masked wave-tile instead runs the
+        // body with thr past every row: P = dS = 0 by select, the MFMAs add exact zeros (outputs bit-identical).  Measured,
+        // whole backward, causal (tools/ab_bwd.py, profiles/r1_bwd_causal_ab.log): 0.60x at 8k/16k, 0.69x at 1k, D=64 0.89x.
+#ifdef FA_TEST_DKDV_SKIP_BRANCH   // tests/test_kernel_resources_cpu.py only: reinstates the branch so the guard can prove it detects it
+        if (!CAUSAL || (wave_k_lo <= mh + 31 + delta))
+#endif
+        {
+            // causal mask, 2 VALU per element: element r = 4*g4 + e is query row m0 + 32*qh + 8*g4 + 4*hi + e, visible iff
+            // key <= row + delta  <=>  8*g4 + e >= thr with everything tile- / lane-dependent folded into `thr` once per
+            // tile (INT_MIN when this wave's tile needs no mask); the left side is a compile-time constant.
             const bool need_mask = CAUSAL && (wave_k_hi > mh + delta);
-            const int key = n0 + key_row;
+            const int thr = need_mask ? (n0 + key_row) - (mh + 4 * hi + delta) : (int)0x80000000;
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv_kernel(const BwdKer
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
                     float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -l4[e]));
-                    if (need_mask) pv = (key <= m0 + rbase + e + delta) ? pv : 0.f;
+                    if constexpr (CAUSAL) pv = (8 * g4 + e >= thr) ? pv : 0.f;
                     pacc[r] = pv;
                     sacc[r] = pv * (dpacc[r] - d4[e]);
                 }

@@ -1,0 +1,77 @@
+"""Compile a .hip file of the package to gfx950 assembly (hipcc cross-compiles without a GPU) and report, per kernel,
+the compiler's own resource usage (-Rpass-analysis=kernel-resource-usage) plus what sits INSIDE its MFMA loops:
+scratch (spill) traffic and v_accvgpr_* register shuffles.  Test infrastructure only."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "flash-attention-turing_amd")
+sys.path.insert(0, PKG)
+import build as _build  # noqa: E402
+
+_KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", r"ScratchSize \[bytes/lane\]": "scratch_bytes", r"Occupancy \[waves/SIMD\]": "occupancy",
+         r"LDS Size \[bytes/block\]": "lds_bytes"}
+
+
+def _loops(body):
+    """(label, text) of every backward-branch region: label ... branch back to that label"""
+    out = []
+    for m in re.finditer(r"^(\.LBB\d+_\d+):", body, re.M):
+        lab, a = m.group(1), m.end()
+        ends = [b.end() for b in re.finditer(r"s_c?branch\w* " + re.escape(lab) + r"\b", body[a:])]
+        if ends:
+            out.append((lab, body[a:a + max(ends)]))
+    return out
+
+
+def analyse(hip_source, extra_flags=()):
+    src = os.path.join(_build.CSRC, hip_source)
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        cmd = [_build.hipcc_path()] + list(_build.HIPCC_FLAGS) + list(extra_flags) + ["-I", _build.CSRC, "-I", _build.INCLUDE, "--cuda-device-only", "-S", src,
+                                                                                      "-o", asm, "-Rpass-analysis=kernel-resource-usage"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-2000:])
+        txt = open(asm).read()
+    kernels, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for pat, key in _KEYS.items():
+            m = re.search(r"\s" + pat + r": (\d+)", line)
+            if m:
+                cur[key] = int(m.group(1))
+    for name, info in kernels.items():
+        if name + ":" not in txt:
+            continue
+        body = txt[txt.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        info["mfma_total"] = len(re.findall(r"v_mfma", body))
+        info["loops"] = []
+        for lab, seg in _loops(body):
+            n = len(re.findall(r"v_mfma", seg))
+            if n >= 8:
+                info["loops"].append({"label": lab, "mfma": n, "scratch_ops": len(re.findall(r"scratch_(?:load|store)", seg)),
+                                      "accvgpr_moves": len(re.findall(r"v_accvgpr_(?:read|write|mov)", seg)),
+                                      "valu": len([1 for x in re.findall(r"^\s+(v_[a-z0-9_]+)", seg, re.M) if "mfma" not in x])})
+    return kernels
+
+
+if __name__ == "__main__":
+    for f in sys.argv[1:] or ["fa_fwd_pp.hip", "fa_fwd.hip", "fa_fwd_sp.hip", "fa_bwd.hip"]:
+        for name, k in analyse(f).items():
+            if "loops" not in k:
+                continue
+            worst = max(k["loops"], key=lambda d: d["mfma"]) if k["loops"] else None
+            inloop = (sum(d["scratch_ops"] for d in k["loops"]), sum(d["accvgpr_moves"] for d in k["loops"]))
+            short = re.sub(r"^_ZN2fa\d+", "", name)[:44]
+            print(f"{f:14s} {short:44s} VGPR {k.get('vgprs'):3d} AGPR {k.get('agprs'):3d} scratch {k.get('scratch_bytes'):4d} B/lane occ {k.get('occupancy')} "
+                  f"| MFMA loops {len(k['loops'])} in-loop scratch ops {inloop[0]:3d} accvgpr moves {inloop[1]:3d}" + (f" | main loop: {worst['mfma']} MFMA, {worst['valu']} VALU" if worst else ""))

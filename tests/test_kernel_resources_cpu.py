@@ -1,0 +1,59 @@
+"""Guard against silent register-allocation pathologies in the HIP kernels (runs on CPU: hipcc cross-compiles gfx950).
+
+Parity tests cannot see a kernel that spills or shuffles its accumulators inside the hot loop -- it is merely slow.  Round 1
+shipped a causal dK/dV kernel with 258 v_accvgpr moves + 48 scratch ops per loop iteration for most of the round (1.65x slower
+backward on causal shapes, profiles/r1_bwd_causal_ab.log) because only the non-causal instance had been inspected.  This test
+compiles every kernel instantiation and fails on scratch traffic or accumulator shuffles inside any MFMA loop."""
+import pytest
+
+from _kernel_isa import analyse
+
+FILES = ["fa_fwd_pp.hip", "fa_fwd.hip", "fa_fwd_sp.hip", "fa_bwd.hip"]
+# whole-kernel scratch that is known, outside every loop (prologue / epilogue), and bounded here so growth is noticed
+SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 64}
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    out = {}
+    for f in FILES:
+        for name, info in analyse(f).items():
+            out[(f, name)] = info
+    return out
+
+
+def test_every_kernel_was_analysed(kernels):
+    with_loops = [k for k, v in kernels.items() if v.get("loops")]
+    assert len(kernels) >= 36 and len(with_loops) >= 32, (len(kernels), len(with_loops))
+    for (f, name), info in kernels.items():
+        assert {"vgprs", "agprs", "scratch_bytes", "occupancy"} <= set(info), (f, name, info)
+
+
+def test_no_spills_or_accumulator_shuffles_inside_mfma_loops(kernels):
+    bad = []
+    for (f, name), info in kernels.items():
+        for loop in info.get("loops", []):
+            if loop["scratch_ops"] or loop["accvgpr_moves"]:
+                bad.append((f, name, loop))
+    assert not bad, bad
+
+
+def test_whole_kernel_scratch_is_zero_or_on_the_allow_list(kernels):
+    for (f, name), info in kernels.items():
+        limit = next((v for k, v in SCRATCH_ALLOWED.items() if k in name), 0)
+        assert info["scratch_bytes"] <= limit, (f, name, info["scratch_bytes"], limit)
+
+
+def test_two_waves_per_simd_for_the_eight_wave_kernels(kernels):
+    for (f, name), info in kernels.items():
+        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_fwd_sp_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel")):
+            assert info["occupancy"] >= 2, (f, name, info["occupancy"])
+
+
+def test_guard_detects_the_known_pathology():
+    """the detector must fire on the construct it exists for: the wave-level skip branch around asm-accumulator MFMAs"""
+    ks = analyse("fa_bwd.hip", extra_flags=["-DFA_TEST_DKDV_SKIP_BRANCH"])
+    causal_d128 = [v for n, v in ks.items() if "fa_bwd_dkdv_kernel" in n and "Li128ELb1" in n]
+    assert causal_d128
+    for info in causal_d128:
+        assert sum(l["accvgpr_moves"] for l in info["loops"]) > 100, info["loops"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved in-process A/B of the whole backward (dot + dQ + dK/dV through fa_mha_bwd) between two builds of the
-library: rounds x {A, B}, median / min / max per build, random data.  Usage: ab_bwd.py A.so B.so [--rounds N]"""
+library: rounds x {A, B}, median / min / max per build, random data.  Usage: ab_bwd.py A.so B.so [C.so ...] [--rounds N]"""
 import argparse
 import ctypes
 import statistics
@@ -19,17 +19,20 @@ def load(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("a")
-    ap.add_argument("b")
+    ap.add_argument("libs", nargs="+", help="two or more builds of libflash_attn_gfx950.so; the first is the baseline")
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--iters", type=int, default=3)
     a = ap.parse_args()
-    libs = {"A:" + a.a.split("/")[-1]: load(a.a), "B:" + a.b.split("/")[-1]: load(a.b)}
+    libs = {f"{chr(65 + i)}:" + p.split("/")[-1]: load(p) for i, p in enumerate(a.libs)}
     dev = torch.device("cuda:0")
     cfgs = {"c4 bf16 d128 8k": (4, 8192, 32, 32, 128, torch.bfloat16, False),
             "bf16 d128 8k causal": (4, 8192, 32, 32, 128, torch.bfloat16, True),
             "fp16 d64 8k": (4, 8192, 32, 32, 64, torch.float16, False),
             "fp16 d128 gqa 4k causal": (4, 4096, 32, 8, 128, torch.float16, True),
+            "bf16 d128 1k causal": (16, 1024, 32, 32, 128, torch.bfloat16, True),
+            "bf16 d128 2k causal": (8, 2048, 32, 32, 128, torch.bfloat16, True),
+            "fp16 d128 16k causal (c3 bwd)": (4, 16384, 32, 32, 128, torch.float16, True),
+            "fp16 d64 8k causal": (4, 8192, 32, 32, 64, torch.float16, True),
             "fp16 d128 ragged 4000x4100": (4, 4000, 32, 32, 128, torch.float16, False)}
     for cname, (b, s, h, hk, d, dt, causal) in cfgs.items():
         sk = 4100 if "ragged" in cname else s
@@ -58,8 +61,7 @@ def main():
         for n in libs:
             run(n)
         torch.cuda.synchronize()
-        (na, nb) = list(libs)
-        same = all(torch.equal(x, y) for x, y in zip(outs[na], outs[nb]))
+        na = list(libs)[0]
         times = {n: [] for n in libs}
         for _ in range(a.rounds):
             for n in libs:
@@ -70,11 +72,13 @@ def main():
                 e1.record()
                 e1.synchronize()
                 times[n].append(e0.elapsed_time(e1) / a.iters)
-        ma, mb = statistics.median(times[na]), statistics.median(times[nb])
+        ma = statistics.median(times[na])
         for n in libs:
             ts = times[n]
-            print(f"{cname:28s} {n:34s} median {statistics.median(ts):8.3f} ms (min {min(ts):8.3f} max {max(ts):8.3f})", flush=True)
-        print(f"{cname:28s} B/A time {mb / ma:6.4f}   dq/dk/dv bit-identical between builds: {same}", flush=True)
+            same = all(torch.equal(x, y) for x, y in zip(outs[na], outs[n]))
+            md = max(float((x.float() - y.float()).abs().max()) for x, y in zip(outs[na], outs[n]))
+            print(f"{cname:30s} {n:30s} median {statistics.median(ts):8.3f} ms (min {min(ts):8.3f} max {max(ts):8.3f})  time vs A {statistics.median(ts) / ma:6.4f}  "
+                  f"bit-identical to A: {same} (max abs diff {md:.3g})", flush=True)
 
 
 if __name__ == "__main__":
