@@ -75,7 +75,15 @@ constexpr int kDqBlockM = 256;
 constexpr int kDqBlockN = 64;
 
 template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kDqThreads, 2) void fa_bwd_dq_kernel(const BwdKernelParams p) {
+// D = 64: ask for 4 waves per SIMD = TWO 8-wave workgroups per CU in dQ and dK/dV (blocks come in units of 2 waves per
+// SIMD; with the default bound the compiler took 171 / 88+64 registers and one workgroup per CU).  At 128 registers dQ
+// non-causal carries 1 scratch op per tile and dK/dV 2-3 (tests/test_kernel_resources_cpu.py allows exactly that, nothing
+// else).  Interleaved A/B of the whole backward, outputs bit-identical (profiles/r1_bwd_d64_occupancy_ab.log): dK/dV alone
+// 0.80-0.90x time, dQ alone 0.90-0.98x, both 0.78-0.83x on every D = 64 shape (8k / 2k / 512, causal or not, GQA); D = 128
+// unchanged (its registers and LDS allow one workgroup per CU only).
+#define FA_DQ_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+#define FA_KV_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+__global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
     constexpr int TILEB = kDqBlockN * ROWB;
     __shared__ __attribute__((aligned(16))) char smem_raw[(4 * TILEB > kDqBlockM * ROWB) ? 4 * TILEB : kDqBlockM * ROWB];
@@ -287,7 +295,7 @@ constexpr int kKvBlockN = 128;   // keys per workgroup (32 per key block, 4 key 
 constexpr int kKvBlockM = 64;    // query rows per staged tile (two 32-row halves)
 
 template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv_kernel(const BwdKernelParams p) {
+__global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
     constexpr int KVB = kKvBlockN * ROWB;                   // the workgroup's K (or V) tile
     constexpr int TILEB = kKvBlockM * ROWB;                 // one Q (or dO) tile

@@ -24,7 +24,12 @@ constexpr int kFwdBlockN = 64;
 constexpr float kPpDeferLog2 = 6.0f;
 
 template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_pp_kernel(const FwdKernelParams p) {
+// D = 64: ask for 4 waves per SIMD = TWO 8-wave workgroups per CU (its LDS rings are half the D = 128 size).  The non-causal
+// instance fitted 128 registers anyway; the causal one took 140 and silently ran one workgroup per CU.  Forcing 128 costs no
+// spill and no extra instruction in any loop; interleaved A/B, causal forward (profiles/r1_fwd_d64_occupancy_ab.log):
+// 0.90-0.93x time at 8k, 0.96x at 16k, 0.75x at 2k, 0.71x at 512; non-causal and D = 128 unchanged; outputs bit-identical.
+#define FA_PP_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+__global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_kernel(const FwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
     constexpr int TILEB = kFwdBlockN * ROWB;
     constexpr int RING = 3;

@@ -10,7 +10,11 @@ from _kernel_isa import analyse
 
 FILES = ["fa_fwd_pp.hip", "fa_fwd.hip", "fa_fwd_sp.hip", "fa_bwd.hip"]
 # whole-kernel scratch that is known, outside every loop (prologue / epilogue), and bounded here so growth is noticed
-SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 64}
+SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 64, "fa_bwd_dq_kernel": 64}
+# scratch ops INSIDE an MFMA loop: zero everywhere except the two D=64 backward kernels, which were deliberately squeezed to
+# 128 registers for two workgroups per CU (0.78-0.83x backward time measured WITH these few spill ops, see fa_bwd.hip and
+# profiles/r1_bwd_d64_occupancy_ab.log).  (kernel substring, head-dim substring) -> max ops per loop.  Accumulator shuffles: never.
+INLOOP_SCRATCH_ALLOWED = {("fa_bwd_dkdv_kernel", "Li64E"): 4, ("fa_bwd_dq_kernel", "Li64E"): 2}
 
 
 @pytest.fixture(scope="module")
@@ -33,8 +37,9 @@ def test_no_spills_or_accumulator_shuffles_inside_mfma_loops(kernels):
     bad = []
     for (f, name), info in kernels.items():
         for loop in info.get("loops", []):
-            if loop["scratch_ops"] or loop["accvgpr_moves"]:
-                bad.append((f, name, loop))
+            limit = next((v for (k, dd), v in INLOOP_SCRATCH_ALLOWED.items() if k in name and dd in name), 0)
+            if loop["scratch_ops"] > limit or loop["accvgpr_moves"]:
+                bad.append((f, name, loop, limit))
     assert not bad, bad
 
 

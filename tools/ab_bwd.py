@@ -22,6 +22,7 @@ def main():
     ap.add_argument("libs", nargs="+", help="two or more builds of libflash_attn_gfx950.so; the first is the baseline")
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--only", default="", help="substring filter on config names")
     a = ap.parse_args()
     libs = {f"{chr(65 + i)}:" + p.split("/")[-1]: load(p) for i, p in enumerate(a.libs)}
     dev = torch.device("cuda:0")
@@ -33,8 +34,14 @@ def main():
             "bf16 d128 2k causal": (8, 2048, 32, 32, 128, torch.bfloat16, True),
             "fp16 d128 16k causal (c3 bwd)": (4, 16384, 32, 32, 128, torch.float16, True),
             "fp16 d64 8k causal": (4, 8192, 32, 32, 64, torch.float16, True),
+            "bf16 d64 2k": (16, 2048, 32, 32, 64, torch.bfloat16, False),
+            "bf16 d64 2k causal": (16, 2048, 32, 32, 64, torch.bfloat16, True),
+            "fp16 d64 512 causal": (64, 512, 32, 32, 64, torch.float16, True),
+            "bf16 d64 8k GQA32/8 causal": (4, 8192, 32, 8, 64, torch.bfloat16, True),
             "fp16 d128 ragged 4000x4100": (4, 4000, 32, 32, 128, torch.float16, False)}
     for cname, (b, s, h, hk, d, dt, causal) in cfgs.items():
+        if a.only and a.only not in cname and "c4" not in cname:
+            continue
         sk = 4100 if "ragged" in cname else s
         gen = torch.Generator(device=dev).manual_seed(1)
         q = torch.randn(b, s, h, d, device=dev, dtype=dt, generator=gen)
