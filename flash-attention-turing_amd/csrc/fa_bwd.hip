@@ -20,6 +20,14 @@
 #include "fa_device.hpp"
 #include "fa_params.hpp"
 
+// FA_ABL_KV: TIMING-ONLY ablations of fa_bwd_dkdv_kernel for tools/ab_bwd.py (results are WRONG when non-zero; build.py never
+// defines it).  bit0: the loop-invariant K / V fragments are read from LDS once per tile instead of once per MFMA;
+// bit1: same for the Q / dO row fragments; bit2: one transposed-read pair per d-block instead of one per MFMA;
+// bit3: no workgroup barrier at the end of a tile (the DMA wait stays).
+#ifndef FA_ABL_KV
+#define FA_ABL_KV 0
+#endif
+
 namespace fa {
 
 // =============================================================================================
@@ -463,18 +471,42 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             const bool need_mask = CAUSAL && (wave_k_hi > mh + delta);
             const int thr = need_mask ? (n0 + key_row) - (mh + 4 * hi + delta) : (int)0x80000000;
             f32x16 sacc, dpacc;
+#if FA_ABL_KV
+            u32x4 abl_a = {0, 0, 0, 0}, abl_b = {0, 0, 0, 0}, abl_t[DB];
+            (void)abl_a; (void)abl_b; (void)abl_t;
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+#if FA_ABL_KV & 2
+                if (ks == 0) abl_a = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
+                const u32x4 qa = abl_a;
+#else
                 const u32x4 qa = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
+#endif
+#if FA_ABL_KV & 1
+                if (ks == 0) abl_b = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
+                const u32x4 kf = abl_b;
+#else
                 const u32x4 kf = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
+#endif
                 sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+#if FA_ABL_KV & 2
+                if (ks == 0) abl_a = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
+                const u32x4 da = abl_a;
+#else
                 const u32x4 da = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
+#endif
+#if FA_ABL_KV & 1
+                if (ks == 0) abl_b = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
+                const u32x4 vf = abl_b;
+#else
                 const u32x4 vf = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
+#endif
                 dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
             }
             f32x16 pacc;
@@ -500,6 +532,16 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 const int ts = 2 * qh + half;                       // 16-row k-slice of the 64-row tile
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
+#if FA_ABL_KV & 4
+                    if (half == 0) {
+                        const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
+                        const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
+                        abl_t[db] = u32x4{a0.x, a0.y, a1.x, a1.y};
+                    }
+                    const u32x4 dot = abl_t[db];
+                    LP<T>::mfma_agpr(dvacc[db], dot, pf);
+                    LP<T>::mfma_agpr(dkacc[db], dot, dsf);
+#else
                     const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
                     const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
                     const u32x4 dot = {a0.x, a0.y, a1.x, a1.y};
@@ -508,12 +550,15 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                     const u32x2 b1 = lds_read_tr8(qbuf, tr_rd[1][db] + ts * 16 * ROWB);
                     const u32x4 qt = {b0.x, b0.y, b1.x, b1.y};
                     LP<T>::mfma_agpr(dkacc[db], qt, dsf);           // dK^T += Q^T dS    (AGPR accumulator)
+#endif
                 }
             }
         }
         if (more) land_stats(buf ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces have landed
+#if !(FA_ABL_KV & 8)
         __syncthreads();
+#endif
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------

@@ -61,7 +61,9 @@ def analyse(hip_source, extra_flags=()):
             if n >= 8:
                 info["loops"].append({"label": lab, "mfma": n, "scratch_ops": len(re.findall(r"scratch_(?:load|store)", seg)),
                                       "accvgpr_moves": len(re.findall(r"v_accvgpr_(?:read|write|mov)", seg)),
-                                      "valu": len([1 for x in re.findall(r"^\s+(v_[a-z0-9_]+)", seg, re.M) if "mfma" not in x])})
+                                      "valu": len([1 for x in re.findall(r"^\s+(v_[a-z0-9_]+)", seg, re.M) if "mfma" not in x]),
+                                      "ds_read_b128": len(re.findall(r"ds_read_b128", seg)), "ds_read_tr": len(re.findall(r"ds_read_b64_tr", seg)),
+                                      "barriers": len(re.findall(r"s_barrier", seg))})
     return kernels
 
 
