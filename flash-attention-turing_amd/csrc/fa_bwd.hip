@@ -23,7 +23,8 @@
 // FA_ABL_KV: TIMING-ONLY ablations of fa_bwd_dkdv_kernel for tools/ab_bwd.py (results are WRONG when non-zero; build.py never
 // defines it).  bit0: the loop-invariant K / V fragments are read from LDS once per tile instead of once per MFMA;
 // bit1: same for the Q / dO row fragments; bit2: one transposed-read pair per d-block instead of one per MFMA;
-// bit3: no workgroup barrier at the end of a tile (the DMA wait stays).
+// bit3: no workgroup barrier at the end of a tile (the DMA wait stays); bit4: that barrier (and the DMA wait) sits between the
+// S and dP MFMAs of the tile instead of at its end (the structure of a 3-deep-Q-ring design, timed on the racy 2-deep ring).
 #ifndef FA_ABL_KV
 #define FA_ABL_KV 0
 #endif
@@ -493,6 +494,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #endif
                 sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
             }
+#if FA_ABL_KV & 16
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#endif
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #if FA_ABL_KV & 2
@@ -555,8 +560,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             }
         }
         if (more) land_stats(buf ^ 1);
+#if !(FA_ABL_KV & 16)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces have landed
-#if !(FA_ABL_KV & 8)
+#endif
+#if !(FA_ABL_KV & (8 | 16))
         __syncthreads();
 #endif
     }
