@@ -10,7 +10,9 @@
 
 // FA_ABL: TIMING-ONLY ablations for tools/ablate_fwd.py (results are WRONG when non-zero; never shipped:
 // build.py does not define it).  bit0: no v_exp in the softmax phase; bit1: no fma/exp/row-sum at all;
-// bit2: the matrix phase reads only every other K / V fragment from LDS (half the LDS bytes per MFMA).
+// bit2: the matrix phase reads only every other K / V fragment from LDS (half the LDS bytes per MFMA);
+// bit3: causal diagonal-band tiles run through the unmasked steady-state loop (what if a band tile cost a full tile?);
+// bit4: no wave-level causal skip inside the band (every wave computes every band tile).
 #ifndef FA_ABL
 #define FA_ABL 0
 #endif
@@ -277,7 +279,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // sequence: no mask, no per-wave skipping -> a branch-free steady-state loop.  The remaining
     // (diagonal / ragged) tiles and the pipeline fill / drain go through the generic body.
     int n_main = min(n_tiles, sk / kFwdBlockN);
+#if !(FA_ABL & 8)
     if (CAUSAL) n_main = min(n_main, max(0, (m0 + delta + 1) / kFwdBlockN));
+#endif
 
     bool prev_active = false;                         // does this wave hold a P tile whose PV is pending?
     // every S phase ends with: this wave's LDS-DMA pieces have landed (vmcnt) -> workgroup barrier
@@ -287,7 +291,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     };
     auto generic_iter = [&](int u) {
         const bool in_range = u < n_tiles;
+#if FA_ABL & 16
+        const bool active = in_range;
+#else
         const bool active = in_range && (!CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta));
+#endif
         if (prev_active) pv_step();
         if (active) qk_step();
         if (!in_range) return;                        // drain iteration: only the pending PV

@@ -18,14 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "flash-attention-turing_amd")
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(ROOT, "tools", "abl")
-VARIANTS = {"base": 0, "noexp": 1, "nosoftmax": 2, "halflds": 4, "halflds+noexp": 5, "halflds+nosoftmax": 6}
+VARIANTS = {"base": 0, "noexp": 1, "nosoftmax": 2, "halflds": 4, "halflds+noexp": 5, "halflds+nosoftmax": 6, "band_as_full": 8, "band_noskip": 16}
 
 
-def build():
+def build(only=None):
     sys.path.insert(0, PKG)
     import build as b
     os.makedirs(OUT, exist_ok=True)
     for name, bits in VARIANTS.items():
+        if only and name not in only:
+            continue
         objs = []
         for src in b.HIP_SOURCES:
             o = os.path.join(OUT, f"{name}_{src}.o")
@@ -43,13 +45,16 @@ def main():
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--variants", default="", help="comma list (default: all)")
+    ap.add_argument("--causal-sweep", action="store_true", help="causal d128 fp16 b4 h32 at 1k..16k instead of the default configs")
     a = ap.parse_args()
     if a.build:
-        return build()
+        return build(a.variants.split(",") if a.variants else None)
     import torch
     vp, i32 = ctypes.c_void_p, ctypes.c_int
     libs = {}
-    for name in VARIANTS:
+    names = [n for n in VARIANTS if not a.variants or n in a.variants.split(",")]
+    for name in names:
         L = ctypes.CDLL(os.path.join(OUT, f"libfa_{name}.so"))
         L.fa_mha_fwd.argtypes = [vp] * 5 + [i32] * 8 + [vp]
         L.fa_mha_fwd.restype = i32
@@ -58,6 +63,8 @@ def main():
     cfgs = {"c3 fp16 d128 causal 16k": (4, 16384, 32, 128, torch.float16, True),
             "nc fp16 d128 8k": (4, 8192, 32, 128, torch.float16, False),
             "nc fp16 d64 8k": (4, 8192, 32, 64, torch.float16, False)}
+    if a.causal_sweep:
+        cfgs = {f"causal fp16 d128 {s_}": (4, s_, 32, 128, torch.float16, True) for s_ in (1024, 2048, 4096, 8192, 16384)}
     for cname, (b, s, h, d, dt, causal) in cfgs.items():
         gen = torch.Generator(device=dev).manual_seed(1)
         q, k, v = (torch.randn(b, s, h, d, device=dev, dtype=dt, generator=gen) for _ in range(3))
