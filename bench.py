@@ -161,27 +161,36 @@ def hbm_traffic_from_profile(workload):
     return None
 
 
+def parse_clockbench(out):
+    """tools/clockbench prints one row per variant: `<label>  <min> <median> <max>` (TFLOP/s over interleaved runs).
+    Returns the best MEDIAN among the pure-MFMA rows, or a dict with `error` so that a format drift is visible in the JSON."""
+    best = None
+    for line in out.splitlines():
+        if not line.startswith("MFMA only"):
+            continue
+        parts = line.split()
+        try:
+            mn, med, mx = (float(x) for x in parts[-3:])
+        except ValueError:
+            continue
+        if best is None or med > best["tflops"]:
+            best = {"tflops": med, "min": mn, "max": mx, "what": " ".join(parts[:-3])}
+    return best if best is not None else {"error": "no 'MFMA only' row with min/median/max in clockbench output", "head": out[:200]}
+
+
 def measured_mfma_ceiling():
-    """tools/clockbench (built by __graft_entry__.build()): sustained clock and TFLOP/s of a chip-wide
-    back-to-back MFMA loop on random operands = what the MFMA roof really is on this box under its
-    power limit.  Reported next to the nominal 2.5 PFLOP/s, never used as `peak`."""
+    """tools/clockbench (built by __graft_entry__.build()): TFLOP/s of a chip-wide back-to-back MFMA loop on random operands
+    = what the MFMA roof really is on this box under its power limit (median of 5 interleaved runs).  Reported next to the
+    nominal 2.5 PFLOP/s, never used as `peak`."""
     import subprocess
 
     exe = os.path.join(ROOT, "tools", "clockbench")
     if not os.path.exists(exe):
-        return None
+        return {"error": "tools/clockbench not built"}
     try:
-        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
-        best = None
-        for line in out.splitlines():
-            if line.startswith("MFMA only"):
-                ghz = float(line.split("->")[1].split("GHz")[0])
-                tf = float(line.split(";")[1].split("TFLOP")[0])
-                if best is None or tf > best["tflops"]:
-                    best = {"tflops": tf, "clock_ghz": ghz, "what": line.split("  ")[0].strip()}
-        return best
-    except Exception:
-        return None
+        return parse_clockbench(subprocess.run([exe], capture_output=True, text=True, timeout=180).stdout)
+    except Exception as e:  # noqa: BLE001 - reported, not hidden
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def cpu_baseline(args):
@@ -339,8 +348,9 @@ def main():
 
     ceiling = measured_mfma_ceiling() if (dist.rank == 0 and dist.world == 1 and not args.no_extra) else None
     if ceiling is not None:
-        roofline["sustained_mfma_peak_measured"] = ceiling
-        roofline["frac_of_sustained_measured"] = k_tflops / ceiling["tflops"]
+        roofline["sustained_mfma_peak_measured"] = ceiling          # carries {"error": ...} instead of vanishing if clockbench fails
+        if "tflops" in ceiling:
+            roofline["frac_of_sustained_measured"] = k_tflops / ceiling["tflops"]
     if dist.rank == 0:
         prop = torch.cuda.get_device_properties(device)
         out = {

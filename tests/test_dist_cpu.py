@@ -61,3 +61,19 @@ def test_gpus_flag_must_match_world_size():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fake-step", "--gpus", "2"], env=env,
                          capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
+
+
+def test_clockbench_parser_reads_the_current_table_and_reports_drift():
+    """bench.py reports the measured MFMA ceiling from tools/clockbench; a format drift must show up in the JSON, not vanish"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    sample = ("variant                                                   min   median      max  (TFLOP/s over 5 interleaved runs)\n"
+              "MFMA only, 1 wave/SIMD                                   1413     1654     1655\n"
+              "MFMA only, 2 waves/SIMD                                  1600     1656     1658\n"
+              "MFMA + 4 VALU, 2 waves/SIMD                              1357     1404     1405\n")
+    got = bench.parse_clockbench(sample)
+    assert got["tflops"] == 1656 and got["min"] == 1600 and "2 waves/SIMD" in got["what"]
+    old_format = "MFMA only, 2 waves/SIMD, all CUs   5.1 ms  s_memtime 8e6 ticks -> 1.6 GHz ; 1650 TFLOP/s ; 32 ticks/MFMA/SIMD\n"
+    assert "error" in bench.parse_clockbench(old_format)
+    assert "error" in bench.parse_clockbench("")

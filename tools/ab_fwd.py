@@ -11,6 +11,7 @@ F16, BF16 = torch.float16, torch.bfloat16
 CONFIGS = {"d64 8k causal fp16": (4, 8192, 32, 32, 64, F16, True), "d64 8k causal bf16": (4, 8192, 32, 32, 64, BF16, True),
            "d64 2k causal fp16": (16, 2048, 32, 32, 64, F16, True), "d64 512 causal fp16": (64, 512, 32, 32, 64, F16, True),
            "d64 8k GQA32/8 causal bf16": (4, 8192, 32, 8, 64, BF16, True), "d64 16k causal fp16": (2, 16384, 32, 32, 64, F16, True),
+           "c3: d128 16k causal fp16": (4, 16384, 32, 32, 128, F16, True), "c2: d128 4k fp16": (4, 4096, 32, 32, 128, F16, False),
            "d64 8k non-causal fp16 (control)": (4, 8192, 32, 32, 64, F16, False), "d128 8k causal fp16 (control)": (4, 8192, 32, 32, 128, F16, True)}
 
 
@@ -19,6 +20,7 @@ def main():
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="", help="substring filter on config names")
     a = ap.parse_args()
     libs = {}
     for i, p in enumerate(a.libs):
@@ -28,6 +30,8 @@ def main():
         libs[f"{chr(65 + i)}:" + p.split("/")[-1]] = L
     dev = torch.device("cuda:0")
     for cname, (b, s, h, hk, d, dt, causal) in CONFIGS.items():
+        if a.only and a.only not in cname:
+            continue
         gen = torch.Generator(device=dev).manual_seed(1)
         q = torch.randn(b, s, h, d, device=dev, dtype=dt, generator=gen)
         k = torch.randn(b, s, hk, d, device=dev, dtype=dt, generator=gen)
