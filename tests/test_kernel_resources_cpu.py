@@ -55,6 +55,18 @@ def test_two_waves_per_simd_for_the_eight_wave_kernels(kernels):
             assert info["occupancy"] >= 2, (f, name, info["occupancy"])
 
 
+def test_d64_kernels_fit_two_workgroups_per_cu(kernels):
+    """D = 64 instances must reach 4 waves per SIMD = two 8-wave workgroups per CU (their LDS allows it); losing it cost 7-29 % forward
+    and 17-22 % backward time in round 1 (profiles/r1_fwd_d64_occupancy_ab.log, r1_bwd_d64_occupancy_ab.log) with parity unaffected"""
+    seen = 0
+    for (f, name), info in kernels.items():
+        if "Li64E" in name and any(k in name for k in ("fa_fwd_pp_kernel", "fa_bwd_dq_kernel", "fa_bwd_dkdv_kernel")):
+            seen += 1
+            assert info["occupancy"] >= 4, (f, name, info["occupancy"], info["vgprs"], info["agprs"])
+            assert 2 * info["lds_bytes"] <= 160 * 1024, (f, name, info["lds_bytes"])
+    assert seen == 12, seen
+
+
 def test_guard_detects_the_known_pathology():
     """the detector must fire on the construct it exists for: the wave-level skip branch around asm-accumulator MFMAs"""
     ks = analyse("fa_bwd.hip", extra_flags=["-DFA_TEST_DKDV_SKIP_BRANCH"])
