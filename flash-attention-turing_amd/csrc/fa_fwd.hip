@@ -36,18 +36,24 @@ constexpr int kFwdThreads = 512;
 constexpr int kFwdBlockM = 256;  // query rows per workgroup (32 per wave)
 constexpr int kFwdBlockN = 64;   // keys per staged tile
 
-template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_kernel(const FwdKernelParams p) {
+// WAVES = 8: the original 512-thread / 256-row workgroup, one per CU.  WAVES = 4 ("simple4"): 256 threads / 128 rows, TWO workgroups
+// per CU (64 KB LDS and <= 256 registers each): the two independent workgroups on a CU decorrelate on their own, which is what
+// short sequences need (few, short workgroups whose prologue / epilogue are otherwise fully exposed); it doubles the L2 -> LDS
+// traffic per unit of work, so it is a candidate for short sequences only.
+template <typename T, int D, bool CAUSAL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void fa_fwd_kernel(const FwdKernelParams p) {
+    constexpr int kFwdThreadsW = 64 * WAVES;    // threads per workgroup
+    constexpr int kFwdBlockMW = 32 * WAVES;     // query rows per workgroup (32 per wave)
     constexpr int KS = D / 16;          // k-steps of the QK^T contraction
     constexpr int DB = D / 32;          // 32-wide d blocks of the O^T accumulator
     constexpr int ROWB = D * 2;         // bytes per staged row
     constexpr int SLOTS = D / 8;        // 16-byte slots per row
     constexpr int TILEB = kFwdBlockN * ROWB;             // bytes per K (or V) tile
-    constexpr int CHUNKS_PER_THREAD = (kFwdBlockN * SLOTS) / kFwdThreads;  // 16B chunks / thread / tile
-    static_assert(CHUNKS_PER_THREAD >= 1, "tile too small for 512 threads");
+    constexpr int CHUNKS_PER_THREAD = (kFwdBlockN * SLOTS) / kFwdThreadsW;  // 16B chunks / thread / tile
+    static_assert(CHUNKS_PER_THREAD >= 1, "tile too small for this many threads");
 
     // LDS: K[2] | V[2]; the O tile (256 x D) aliases the whole region in the epilogue.
-    __shared__ __attribute__((aligned(16))) char smem_raw[(4 * TILEB > kFwdBlockM * ROWB) ? 4 * TILEB : kFwdBlockM * ROWB];
+    __shared__ __attribute__((aligned(16))) char smem_raw[(4 * TILEB > kFwdBlockMW * ROWB) ? 4 * TILEB : kFwdBlockMW * ROWB];
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
 
     const int tid = threadIdx.x;
@@ -76,11 +82,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_kernel(const FwdKernelP
         k_row0 = k_beg;
         q_boff = k_boff = v_boff = o_boff = 0;
     }
-    const int m0 = tile * kFwdBlockM;
+    const int m0 = tile * kFwdBlockMW;
     if (m0 >= sq) return;                // tile beyond this sequence (flash_fwd_kernel.h:55-57)
 
     const int delta = sk - sq;           // causal: key j visible to query i iff j <= i + delta
-    const int rows_here = min(kFwdBlockM, sq - m0);
+    const int rows_here = min(kFwdBlockMW, sq - m0);
 
     const T* q_base = uniform_ptr((const T*)p.q_ptr + q_boff + (q_row0 + m0) * p.q.row + (int64_t)head * p.q.head);
     const T* k_base = uniform_ptr((const T*)p.k_ptr + k_boff + k_row0 * p.k.row + (int64_t)head_k * p.k.head);
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_kernel(const FwdKernelP
     uint32_t st_goff_k[CHUNKS_PER_THREAD], st_goff_v[CHUNKS_PER_THREAD], st_loff[CHUNKS_PER_THREAD];
 #pragma unroll
     for (int c = 0; c < CHUNKS_PER_THREAD; ++c) {
-        const int chunk = tid + c * kFwdThreads;
+        const int chunk = tid + c * kFwdThreadsW;
         const int row = chunk / SLOTS, slot = chunk % SLOTS;
         st_goff_k[c] = row * k_rowb + slot * 16;
         st_goff_v[c] = row * v_rowb + slot * 16;
@@ -277,10 +283,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fa_fwd_kernel(const FwdKernelP
             lds_write8(smem, lds_tile_off<D>(q_row, 4 * db + g4) + 8 * hi, w);
         }
     __syncthreads();
-    constexpr int O_CHUNKS = (kFwdBlockM * SLOTS) / kFwdThreads;
+    constexpr int O_CHUNKS = (kFwdBlockMW * SLOTS) / kFwdThreadsW;
 #pragma unroll
     for (int i = 0; i < O_CHUNKS; ++i) {
-        const int chunk = tid + i * kFwdThreads;
+        const int chunk = tid + i * kFwdThreadsW;
         const int row = chunk / SLOTS, slot = chunk % SLOTS;
         const u32x4 val = lds_read16(smem, lds_tile_off<D>(row, slot));
         buf_store16(o_rs, (uint32_t)row * o_rowb + slot * 16, val);   // rows >= rows_here fall outside the SRD
@@ -299,6 +305,7 @@ static int fwd_impl() {
         const char* e = getenv("FA_FWD_IMPL");
         if (e != nullptr && strcmp(e, "simple") == 0) return 0;
         if (e != nullptr && strcmp(e, "sp") == 0) return 2;
+        if (e != nullptr && strcmp(e, "simple4") == 0) return 3;
         return 1;
     }();
     return impl;
@@ -306,27 +313,32 @@ static int fwd_impl() {
 static int g_fwd_impl_override = -1;
 void set_fwd_impl(int impl) { g_fwd_impl_override = impl; }
 
-template <typename T, int D>
+template <typename T, int D, int WAVES>
 static hipError_t launch_fwd_t(const FwdKernelParams& kp, hipStream_t stream) {
     const uint32_t grid = kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     if (grid == 0) return hipSuccess;
     if (kp.is_causal)
-        hipLaunchKernelGGL((fa_fwd_kernel<T, D, true>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        hipLaunchKernelGGL((fa_fwd_kernel<T, D, true, WAVES>), dim3(grid), dim3(64 * WAVES), 0, stream, kp);
     else
-        hipLaunchKernelGGL((fa_fwd_kernel<T, D, false>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        hipLaunchKernelGGL((fa_fwd_kernel<T, D, false, WAVES>), dim3(grid), dim3(64 * WAVES), 0, stream, kp);
     return hipGetLastError();
+}
+template <int WAVES>
+static hipError_t launch_fwd_w(FwdKernelParams kp, int dtype, hipStream_t stream) {
+    kp.n_q_tiles = (uint32_t)((kp.seqlen_q + 32 * WAVES - 1) / (32 * WAVES));
+    if (dtype == 0) {
+        return kp.d == 128 ? launch_fwd_t<_Float16, 128, WAVES>(kp, stream) : launch_fwd_t<_Float16, 64, WAVES>(kp, stream);
+    } else {
+        return kp.d == 128 ? launch_fwd_t<__bf16, 128, WAVES>(kp, stream) : launch_fwd_t<__bf16, 64, WAVES>(kp, stream);
+    }
 }
 
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     const int impl = g_fwd_impl_override >= 0 ? g_fwd_impl_override : fwd_impl();
     if (impl == 1) return launch_fwd_pp(kp, dtype, stream);
     if (impl == 2) return launch_fwd_sp(kp, dtype, stream);
-    kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
-    if (dtype == 0) {
-        return kp.d == 128 ? launch_fwd_t<_Float16, 128>(kp, stream) : launch_fwd_t<_Float16, 64>(kp, stream);
-    } else {
-        return kp.d == 128 ? launch_fwd_t<__bf16, 128>(kp, stream) : launch_fwd_t<__bf16, 64>(kp, stream);
-    }
+    if (impl == 3) return launch_fwd_w<4>(kp, dtype, stream);
+    return launch_fwd_w<8>(kp, dtype, stream);
 }
 
 }  // namespace fa

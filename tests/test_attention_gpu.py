@@ -29,9 +29,9 @@ def run_hip(g_or_tensors, gpu, causal, dtype, varlen=None):
     return tuple(t.float().cpu().numpy() for t in (o, lse, dq, dk, dv))
 
 
-@pytest.fixture(params=["pp", "simple", "sp"])
+@pytest.fixture(params=["pp", "simple", "sp", "simple4"])
 def fwd_impl(request):
-    """both forward schedules (ping-pong = shipped default, simple = bisecting aid) must be correct"""
+    """every forward schedule (ping-pong = shipped default; simple = bisecting aid; sp; simple4 = 4-wave / 128-row workgroups) must be correct"""
     from flash_attn_turing import capi
 
     capi.set_fwd_impl(request.param)

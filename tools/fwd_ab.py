@@ -21,6 +21,14 @@ CONFIGS = {
     "gqa_8k": (4, 8192, 32, 8, 128, torch.float16, True),
     "s1k": (4, 1024, 32, 32, 128, torch.float16, False),
 }
+# the north_star's sweep: b4 h32 d128 fp16, seq 512..16k, non-causal and causal (+ d64 and a larger batch at 512)
+for _s in (512, 1024, 2048, 4096, 8192, 16384):
+    CONFIGS[f"nc{_s}"] = (4, _s, 32, 32, 128, torch.float16, False)
+    CONFIGS[f"ca{_s}"] = (4, _s, 32, 32, 128, torch.float16, True)
+    CONFIGS[f"d64nc{_s}"] = (4, _s, 32, 32, 64, torch.float16, False)
+    CONFIGS[f"d64ca{_s}"] = (4, _s, 32, 32, 64, torch.float16, True)
+CONFIGS["b64nc512"] = (64, 512, 32, 32, 128, torch.float16, False)
+CONFIGS["b64ca512"] = (64, 512, 32, 32, 128, torch.float16, True)
 
 
 def main():
