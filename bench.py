@@ -60,7 +60,9 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = backend
-        self.enabled = self.world > 1
+        # FA_BENCH_FORCE_PG=1: create the process group even at world size 1, so that the real nccl (= RCCL) init / barrier / all_reduce
+        # calls of the N > 1 path can be exercised on a 1-GPU box (RCCL refuses two ranks on one device)
+        self.enabled = self.world > 1 or os.environ.get("FA_BENCH_FORCE_PG") == "1"
         if self.enabled:
             import torch.distributed as dist
 
