@@ -28,6 +28,11 @@
 #ifndef FA_ABL_KV
 #define FA_ABL_KV 0
 #endif
+// FA_ABL_DQ: the same for fa_bwd_dq_kernel.  bit0: no workgroup barrier per tile; bit1: no exp / dS arithmetic (dS := S);
+// bit2: K / V row fragments and K^T transposed fragments read for every other MFMA only.
+#ifndef FA_ABL_DQ
+#define FA_ABL_DQ 0
+#endif
 
 namespace fa {
 
@@ -211,7 +216,9 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
         const int n0 = t * kDqBlockN;
         FA_LDS char* kbuf = smem + (t & 1) * TILEB;
         FA_LDS char* vbuf = smem + 2 * TILEB + (t & 1) * TILEB;
+#if !(FA_ABL_DQ & 1)
         __syncthreads();      // tile t is in LDS (every wave waited for its pieces); buffer (t+1)&1 is free again
+#endif
         if (t + 1 < n_tiles) dma_tiles(t + 1, (t + 1) & 1);
         const bool wave_active = !CAUSAL || (n0 <= wave_q_hi + delta);
         if (wave_active) {
@@ -227,24 +234,41 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi) {           // two 32-key halves, keeps S/dP at 16+16 regs
                 f32x16 sacc, dpacc;
+#if FA_ABL_DQ & 4
+                u32x4 abl_f = {0, 0, 0, 0};
+#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
+#if FA_ABL_DQ & 4
+                    if ((ks & 1) == 0) abl_f = lds_read16(kbuf, row_rd[ks] + bi * 32 * ROWB);
+                    const u32x4 kf = abl_f;
+#else
                     const u32x4 kf = lds_read16(kbuf, row_rd[ks] + bi * 32 * ROWB);
+#endif
                     sacc = LP<T>::mfma(kf, qf[ks], sacc);          // S^T = K Q^T
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
+#if FA_ABL_DQ & 4
+                    if ((ks & 1) == 0) abl_f = lds_read16(vbuf, row_rd[ks] + bi * 32 * ROWB);
+                    const u32x4 vf = abl_f;
+#else
                     const u32x4 vf = lds_read16(vbuf, row_rd[ks] + bi * 32 * ROWB);
+#endif
                     dpacc = LP<T>::mfma(vf, dof[ks], dpacc);       // dP^T = V dO^T
                 }
                 // P = exp(s*scale - LSE) (flash_bwd_kernel.h:474), dS = P * (dP - D) (:490)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if FA_ABL_DQ & 2
+                    sacc[r] = sacc[r] + dpacc[r];
+#else
                     float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -lse2));
                     pv = (32 * bi + (r & 3) + 8 * (r >> 2)) <= lim_loc ? pv : 0.f;
                     sacc[r] = pv * (dpacc[r] - dsum);
+#endif
                 }
                 // dQ^T (D x 32 queries) += K^T (D x 32 keys) * dS^T (32 keys x 32 queries)
 #pragma unroll
@@ -253,9 +277,18 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
                     const int ts = 2 * bi + half;
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
+#if FA_ABL_DQ & 4
+                        if ((db & 1) == 0) {
+                            const u32x2 a0 = lds_read_tr8(kbuf, tr_rd[0][db] + ts * 16 * ROWB);
+                            const u32x2 a1 = lds_read_tr8(kbuf, tr_rd[1][db] + ts * 16 * ROWB);
+                            abl_f = u32x4{a0.x, a0.y, a1.x, a1.y};
+                        }
+                        const u32x4 ktf = abl_f;
+#else
                         const u32x2 a0 = lds_read_tr8(kbuf, tr_rd[0][db] + ts * 16 * ROWB);
                         const u32x2 a1 = lds_read_tr8(kbuf, tr_rd[1][db] + ts * 16 * ROWB);
                         const u32x4 ktf = {a0.x, a0.y, a1.x, a1.y};
+#endif
                         dqacc[db] = LP<T>::mfma(ktf, dsf, dqacc[db]);
                     }
                 }
