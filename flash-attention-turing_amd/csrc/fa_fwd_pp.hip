@@ -12,7 +12,8 @@
 // build.py does not define it).  bit0: no v_exp in the softmax phase; bit1: no fma/exp/row-sum at all;
 // bit2: the matrix phase reads only every other K / V fragment from LDS (half the LDS bytes per MFMA);
 // bit3: causal diagonal-band tiles run through the unmasked steady-state loop (what if a band tile cost a full tile?);
-// bit4: no wave-level causal skip inside the band (every wave computes every band tile).
+// bit4: no wave-level causal skip inside the band (every wave computes every band tile);
+// bit5: no epilogue output (O staging + stores, LSE) - where does the per-workgroup fixed cost sit?; bit6: no Q load from HBM.
 #ifndef FA_ABL
 #define FA_ABL 0
 #endif
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 
     u32x4 qf[KS];
 #pragma unroll
+#if FA_ABL & 64
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = u32x4{(uint32_t)tid * 0x3c003c00u, 0x3c003c00u + ks, (uint32_t)lane, 0x38003800u};
+#else
     for (int ks = 0; ks < KS; ++ks) qf[ks] = buf_load16(q_rs, (uint32_t)q_row * q_rowb + (2 * ks + hi) * 16);
+#endif
 
     f32x16 oacc[DB];
 #pragma unroll
@@ -336,6 +341,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     const float l_tot = sum_both_halves(l_run);
     const float inv = l_tot > 0.f ? fast_rcp(l_tot) : 0.f;
     const float lse = l_tot > 0.f ? (m_run * c + fast_log2(l_tot)) * kLn2 : 0.f;
+#if FA_ABL & 32
+    {   // keep the whole computation alive with a data-dependent, never-taken store
+        float chk = lse;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk += oacc[db][r] * inv;
+        if (chk == 12345.678f) lse_base[q_row] = chk;
+        return;
+    }
+#endif
     if (hi == 0 && q_row < rows_here) lse_base[q_row] = lse;
     __syncthreads();
 #pragma unroll

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "flash-attention-turing_amd")
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(ROOT, "tools", "abl")
-VARIANTS = {"base": 0, "noexp": 1, "nosoftmax": 2, "halflds": 4, "halflds+noexp": 5, "halflds+nosoftmax": 6, "band_as_full": 8, "band_noskip": 16}
+VARIANTS = {"base": 0, "noexp": 1, "nosoftmax": 2, "halflds": 4, "halflds+noexp": 5, "halflds+nosoftmax": 6, "band_as_full": 8, "band_noskip": 16, "no_epilogue": 32, "no_q_load": 64, "no_epilogue+no_q_load": 96}
 
 
 def build(only=None):
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--variants", default="", help="comma list (default: all)")
     ap.add_argument("--causal-sweep", action="store_true", help="causal d128 fp16 b4 h32 at 1k..16k instead of the default configs")
+    ap.add_argument("--short-sweep", action="store_true", help="d128 fp16 b4 h32 (and b64 at 512) at 512..4k, non-causal and causal")
     a = ap.parse_args()
     if a.build:
         return build(a.variants.split(",") if a.variants else None)
@@ -65,6 +66,12 @@ def main():
             "nc fp16 d64 8k": (4, 8192, 32, 64, torch.float16, False)}
     if a.causal_sweep:
         cfgs = {f"causal fp16 d128 {s_}": (4, s_, 32, 128, torch.float16, True) for s_ in (1024, 2048, 4096, 8192, 16384)}
+    if a.short_sweep:
+        cfgs = {}
+        for s_ in (512, 1024, 2048, 4096):
+            cfgs[f"nc fp16 d128 b4 {s_}"] = (4, s_, 32, 128, torch.float16, False)
+            cfgs[f"causal fp16 d128 b4 {s_}"] = (4, s_, 32, 128, torch.float16, True)
+        cfgs["nc fp16 d128 b64 512"] = (64, 512, 32, 128, torch.float16, False)
     for cname, (b, s, h, d, dt, causal) in cfgs.items():
         gen = torch.Generator(device=dev).manual_seed(1)
         q, k, v = (torch.randn(b, s, h, d, device=dev, dtype=dt, generator=gen) for _ in range(3))
