@@ -134,15 +134,22 @@ def make_inputs(torch, device, b, s, h, hk, d, dtype, seed, backward):
     return t
 
 
-def event_time_ms(torch, fn, iters):
-    """average ms per call, HIP events on torch's current stream (the stream the C ABI launches on)"""
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
-        fn()
-    end.record()
-    end.synchronize()
-    return start.elapsed_time(end) / iters
+def event_time_ms(torch, fn, iters, reps=1):
+    """ms per call, HIP events on torch's current stream (the stream the C ABI launches on): the mean over `iters` back-to-back
+    calls; with reps > 1 the MEDIAN of `reps` such means (single 5-call samples of the `extra` configs were seen 5-7 % off on some
+    boxes of the pool while the kernels were byte-identical)."""
+    import statistics
+
+    means = []
+    for _ in range(reps):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            fn()
+        end.record()
+        end.synchronize()
+        means.append(start.elapsed_time(end) / iters)
+    return statistics.median(means)
 
 
 def hbm_traffic_from_profile(workload):
@@ -311,14 +318,14 @@ def main():
             et = make_inputs(torch, device, eb, es, eh, ehk, ed, edt, 4321, ebwd)
             f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], ec)
             f(); sync()
-            ms = event_time_ms(torch, f, 10)
+            ms = event_time_ms(torch, f, 5, reps=5)
             ff = fwd_flops(eb, es, es, eh, ed, ec)
             extra[name] = {"fwd_ms": ms, "fwd_tflops": ff / ms / 1e9, "fwd_frac_peak": ff / ms / 1e9 / PEAK_DENSE_FP16_TFLOPS}
             if ebwd:
                 g = lambda: capi.mha_bwd(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"],
                                          et["dv"], et["dsum"], ec)
                 g(); sync()
-                bms = event_time_ms(torch, g, 5)
+                bms = event_time_ms(torch, g, 3, reps=5)
                 extra[name].update({"bwd_ms": bms, "bwd_tflops": 2.5 * ff / bms / 1e9,
                                     "fwd_bwd_tflops": 3.5 * ff / (ms + bms) / 1e9})
             del et
