@@ -132,3 +132,41 @@ def test_varlen_random_batches_with_empty_sequences(gpu, case):
         _check((o[qs], dq[qs], dk[ks], dv[ks]), (o_r[0], dq_r[0], dk_r[0], dv_r[0]), dt, tag)
         assert (lse[i, :, : lq[i]] - lse_r[0]).abs().max().item() <= U.LSE_TOL, "LSE " + tag
         assert (lse[i, :, lq[i]:] == 0).all(), "padded LSE must stay zero " + tag
+
+
+_LARGE = [(2049, 2049), (3001, 4099), (4099, 3001), (5000, 8191), (8191, 5000), (9001, 9001), (1, 8191), (8191, 1), (4099, 63), (63, 4099), (6007, 2050), (2050, 6007)]
+
+
+@pytest.mark.parametrize("case", range(len(_LARGE) * 2))
+def test_dense_large_odd_shapes(gpu, case):
+    """many-tile loops with ragged tails: odd lengths of several thousand, GQA, both dtypes / head dims, causal and not"""
+    import flash_attn_turing as F
+
+    sq, sk = _LARGE[case // 2]
+    causal = bool(case % 2)
+    rng = np.random.default_rng(3000 + case)
+    h, hk = _heads(rng)
+    d = int(rng.choice([64, 128]))
+    dt = ("fp16", "bf16")[(case // 2) % 2]
+    tdt = U.torch_dtype(dt)
+    gen = torch.Generator(device="cpu").manual_seed(11000 + case)
+    q = torch.randn(1, sq, h, d, generator=gen).to(gpu, tdt)
+    k = torch.randn(1, sk, hk, d, generator=gen).to(gpu, tdt)
+    v = torch.randn(1, sk, hk, d, generator=gen).to(gpu, tdt)
+    do = torch.randn(1, sq, h, d, generator=gen).to(gpu, tdt)
+    tag = f"[large case {case}: sq{sq} sk{sk} h{h}/{hk} d{d} {dt} causal={causal}]"
+    if sq * sk <= 256 * 257:
+        from oracle import attn_oracle as A
+
+        mode = A.ROUND_FP16 if dt == "fp16" else A.ROUND_BF16
+        n = lambda t: t.float().cpu().numpy()
+        o_n, lse_n = A.attn_fwd(n(q), n(k), n(v), causal=causal, round_mode=mode)
+        dq_n, dk_n, dv_n = A.attn_bwd(n(q), n(k), n(v), o_n, lse_n, n(do), causal=causal, round_mode=mode)
+        o_r, lse_r, dq_r, dk_r, dv_r = (torch.from_numpy(x).to(gpu) for x in (o_n, lse_n, dq_n, dk_n, dv_n))
+        tag += " vs C oracle"
+    else:
+        o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, causal)
+    o, lse = F.fwd(q, k, v, causal)
+    dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
+    _check((o, dq, dk, dv), (o_r, dq_r, dk_r, dv_r), dt, tag)
+    assert (lse - lse_r).abs().max().item() <= U.LSE_TOL, "LSE " + tag
