@@ -170,3 +170,64 @@ def test_dense_large_odd_shapes(gpu, case):
     dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
     _check((o, dq, dk, dv), (o_r, dq_r, dk_r, dv_r), dt, tag)
     assert (lse - lse_r).abs().max().item() <= U.LSE_TOL, "LSE " + tag
+
+
+def _layouts(b, s_q, s_k, h, hk, d, tdt, gpu, gen):
+    """name -> (q, k, v, dout) views over differently laid-out storage, all with the same VALUES as the contiguous base set"""
+    base = {n: torch.randn(*shape, generator=gen).to(gpu, tdt) for n, shape in
+            (("q", (b, s_q, h, d)), ("k", (b, s_k, hk, d)), ("v", (b, s_k, hk, d)), ("dout", (b, s_q, h, d)))}
+
+    def bhsd(t):          # (b, h, s, d) storage viewed as (b, s, h, d): the layout torch SDPA users hold
+        return t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+
+    def sbhd(t):          # (s, b, h, d) storage
+        return t.permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3)
+
+    def padded(t, ps, ph, pd, off):
+        bb, ss, hh, dd = t.shape
+        buf = torch.zeros(bb, ss + ps + off, hh + ph, dd + pd, device=t.device, dtype=t.dtype)
+        view = buf[:, off:off + ss, :hh, :dd]
+        view.copy_(t)
+        return view
+
+    out = {"contiguous": tuple(base[n] for n in ("q", "k", "v", "dout")),
+           "bhsd storage": tuple(bhsd(base[n]) for n in ("q", "k", "v", "dout")),
+           "sbhd storage": tuple(sbhd(base[n]) for n in ("q", "k", "v", "dout")),
+           "padded, aligned (row/head pitch d+8, 1 row in)": tuple(padded(base[n], 3, 1, 8, 1) for n in ("q", "k", "v", "dout")),
+           "padded, UNALIGNED head pitch d+4 (wrapper must copy)": tuple(padded(base[n], 0, 0, 4, 0) for n in ("q", "k", "v", "dout"))}
+    kv = torch.stack((base["k"], base["v"]), dim=2)                      # (b, s_k, 2, hk, d) packed KV
+    out["packed kv"] = (base["q"], kv[:, :, 0], kv[:, :, 1], base["dout"])
+    if h == hk and s_q == s_k:
+        qkv = torch.stack((base["q"], base["k"], base["v"]), dim=2)       # (b, s, 3, h, d) packed QKV
+        out["packed qkv"] = (qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], base["dout"])
+    return out
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_strided_views_are_bit_identical_to_contiguous(gpu, case):
+    """the kernels take real strides: any accepted layout must give exactly the contiguous result, forward and backward"""
+    import flash_attn_turing as F
+
+    rng = np.random.default_rng(4000 + case)
+    b = int(rng.integers(1, 4))
+    s_q = int(rng.choice([1, 63, 128, 257, 700]))
+    s_k = s_q if case % 2 == 0 else int(rng.choice([1, 65, 300, 513]))
+    h, hk = _heads(rng)
+    if case % 2 == 0:
+        hk = h                                 # exercise packed qkv
+    d = int(rng.choice([64, 128]))
+    dt = ("fp16", "bf16")[case % 2]
+    causal = bool(rng.integers(0, 2))
+    gen = torch.Generator(device="cpu").manual_seed(13000 + case)
+    lay = _layouts(b, s_q, s_k, h, hk, d, U.torch_dtype(dt), gpu, gen)
+    ref = None
+    for name, (q, k, v, do) in lay.items():
+        o, lse = F.fwd(q, k, v, causal)
+        dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
+        got = (o, lse, dq, dk, dv)
+        if ref is None:
+            ref = got
+            continue
+        for g, r, tname in zip(got, ref, ("O", "LSE", "dQ", "dK", "dV")):
+            assert torch.equal(g, r), f"{tname} differs for layout '{name}' [case {case}: b{b} sq{s_q} sk{s_k} h{h}/{hk} d{d} {dt} causal={causal}] " \
+                                      f"max|diff| {(g.float() - r.float()).abs().max().item():.3e}"
