@@ -47,7 +47,12 @@ template <typename T, int D>
 __global__ __launch_bounds__(kDotThreads) void fa_bwd_dot_do_o_kernel(const BwdKernelParams p) {
     constexpr int LPR = D / 8;                       // lanes per row
     constexpr int RPI = kDotThreads / LPR;           // rows per iteration
-    const int batch = blockIdx.z, head = blockIdx.y;
+    int batch = blockIdx.z, mblk = blockIdx.x;
+    const int head = blockIdx.y;
+    if (p.varlen_slots != 0) {       // compact varlen grid: blockIdx.x = slot, blockIdx.z = 0
+        int nt;
+        if (!varlen_slot_lookup<kDotRowsPerBlock>(p.cu_seqlens_q, p.b, blockIdx.x, batch, mblk, nt)) return;
+    }
     int sq = p.seqlen_q;
     int64_t row0 = 0, o_boff = (int64_t)batch * p.o.batch, do_boff = (int64_t)batch * p.dout.batch;
     if (p.cu_seqlens_q != nullptr) {
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(kDotThreads) void fa_bwd_dot_do_o_kernel(const BwdK
         row0 = beg;
         o_boff = do_boff = 0;
     }
-    const int m0 = blockIdx.x * kDotRowsPerBlock;
+    const int m0 = mblk * kDotRowsPerBlock;
     if (m0 >= sq) return;
     const T* o_base = (const T*)p.o_ptr + o_boff + row0 * p.o.row + (int64_t)head * p.o.head;
     const T* do_base = (const T*)p.do_ptr + do_boff + row0 * p.dout.row + (int64_t)head * p.dout.head;
@@ -106,10 +111,10 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    uint32_t tile, bh;
-    decode_block(blockIdx.x, p.n_q_tiles, (uint32_t)(p.b * p.h), tile, bh);
-    if (CAUSAL) tile = p.n_q_tiles - 1 - tile;
-    const int batch = bh / p.h, head = bh % p.h, head_k = head / p.h_ratio;
+    int tile, batch, head, tiles_seq;
+    if (!decode_work<kDqBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (CAUSAL) tile = tiles_seq - 1 - tile;
+    const int head_k = head / p.h_ratio;
 
     int sq = p.seqlen_q, sk = p.seqlen_k;
     int64_t q_row0 = 0, k_row0 = 0;
@@ -353,9 +358,8 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb = wave & 3, qh = wave >> 2;             // key block / q-half of this wave
 
-    uint32_t tile, bhk;
-    decode_block(blockIdx.x, p.n_k_tiles, (uint32_t)(p.b * p.h_k), tile, bhk);
-    const int batch = bhk / p.h_k, head_k = bhk % p.h_k;
+    int tile, batch, head_k, tiles_seq;     // tile = 128-key block of this sequence (compact varlen grid: looked up in cu_seqlens_k)
+    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k, tile, batch, head_k, tiles_seq)) return;
 
     int sq = p.seqlen_q, sk = p.seqlen_k;
     int64_t q_row0 = 0, k_row0 = 0;
@@ -650,13 +654,14 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
 static hipError_t launch_dot_t(const BwdKernelParams& kp, hipStream_t s) {
-    dim3 grid((kp.seqlen_q + kDotRowsPerBlock - 1) / kDotRowsPerBlock, kp.h, kp.b);
+    const uint32_t tiles = (uint32_t)((kp.seqlen_q + kDotRowsPerBlock - 1) / kDotRowsPerBlock);
+    dim3 grid(kp.varlen_slots != 0 ? kp.varlen_slots : tiles, kp.h, kp.varlen_slots != 0 ? 1 : kp.b);
     hipLaunchKernelGGL((fa_bwd_dot_do_o_kernel<T, D>), grid, dim3(kDotThreads), 0, s, kp);
     return hipGetLastError();
 }
 template <typename T, int D>
 static hipError_t launch_dq_t(const BwdKernelParams& kp, hipStream_t s) {
-    const uint32_t grid = kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
+    const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     if (grid == 0) return hipSuccess;
     if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, true>), dim3(grid), dim3(kDqThreads), 0, s, kp);
     else hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, false>), dim3(grid), dim3(kDqThreads), 0, s, kp);
@@ -664,7 +669,7 @@ static hipError_t launch_dq_t(const BwdKernelParams& kp, hipStream_t s) {
 }
 template <typename T, int D>
 static hipError_t launch_dkdv_t(const BwdKernelParams& kp, hipStream_t s) {
-    const uint32_t grid = kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k;
+    const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h_k : kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k;
     if (grid == 0) return hipSuccess;
     if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
     else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
@@ -675,13 +680,19 @@ static hipError_t launch_dkdv_t(const BwdKernelParams& kp, hipStream_t s) {
     ((dtype) == 0 ? ((kp).d == 128 ? FN<_Float16, 128>(kp, s) : FN<_Float16, 64>(kp, s))           \
                   : ((kp).d == 128 ? FN<__bf16, 128>(kp, s) : FN<__bf16, 64>(kp, s)))
 
-hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t s) { return FA_DISPATCH(launch_dot_t, kp, dtype, s); }
+hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t s) {
+    const uint32_t tiles = (uint32_t)((kp.seqlen_q + kDotRowsPerBlock - 1) / kDotRowsPerBlock);
+    kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDotRowsPerBlock, tiles) : 0u;
+    return FA_DISPATCH(launch_dot_t, kp, dtype, s);
+}
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);
+    kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
 hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_k_tiles = (uint32_t)((kp.seqlen_k + kKvBlockN - 1) / kKvBlockN);
+    kp.varlen_slots = kp.cu_seqlens_k != nullptr ? varlen_slot_count(kp.total_k, kp.b, kKvBlockN, kp.n_k_tiles) : 0u;
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

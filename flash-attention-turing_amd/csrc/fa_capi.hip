@@ -65,7 +65,9 @@ const char* fa_last_error(void) { return g_err; }
 /* debug / A-B timing hook, not part of the public header: selects the forward schedule */
 void fa_debug_set_fwd_impl(int impl) { fa::set_fwd_impl(impl); }
 
-const char* fa_build_info(void) { return "flash_attn_gfx950 abi=1 arch=gfx950 mfma=32x32x16 wave64 built " __DATE__; }
+#define FA_STR2(x) #x
+#define FA_STR(x) FA_STR2(x)
+const char* fa_build_info(void) { return "flash_attn_gfx950 abi=" FA_STR(FA_ABI_VERSION) " arch=gfx950 mfma=32x32x16 wave64 built " __DATE__; }
 
 double fa_fwd_flops(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t d, int32_t is_causal) {
     double pairs;
@@ -115,6 +117,8 @@ int fa_run_mha_fwd(const fa_fwd_params* p, void* stream) {
     kp.b = p->b; kp.seqlen_q = p->seqlen_q; kp.seqlen_k = p->seqlen_k;
     kp.h = p->h; kp.h_k = p->h_k; kp.h_ratio = p->h / p->h_k; kp.d = p->d;
     kp.is_causal = p->is_causal ? 1 : 0;
+    if (p->total_q < 0 || p->total_k < 0) return fail(FA_ERR_BAD_SHAPE, "total_q / total_k must be >= 0 (0 = unknown)");
+    kp.total_q = varlen ? p->total_q : 0;          // sizes the varlen launch grid by the tokens present (fa_device.hpp)
     kp.scale = 1.0f / sqrtf((float)p->d);          // hard-wired like the reference (flash_fwd_kernel.h:351)
     kp.scale_log2e = kp.scale * 1.4426950408889634f;
     return hip_status(fa::launch_fwd(kp, p->dtype, (hipStream_t)stream), "fa_fwd launch");
@@ -151,6 +155,8 @@ static int fill_bwd(const fa_bwd_params* p, fa::BwdKernelParams& kp) {
     kp.b = p->b; kp.seqlen_q = p->seqlen_q; kp.seqlen_k = p->seqlen_k;
     kp.h = p->h; kp.h_k = p->h_k; kp.h_ratio = p->h / p->h_k; kp.d = p->d;
     kp.is_causal = p->is_causal ? 1 : 0;
+    if (p->total_q < 0 || p->total_k < 0) return fail(FA_ERR_BAD_SHAPE, "total_q / total_k must be >= 0 (0 = unknown)");
+    if (p->cu_seqlens_q != nullptr) { kp.total_q = p->total_q; kp.total_k = p->total_k; }
     kp.scale = 1.0f / sqrtf((float)p->d);
     kp.scale_log2e = kp.scale * 1.4426950408889634f;
     return FA_OK;

@@ -32,9 +32,7 @@
 
 namespace fa {
 
-constexpr int kFwdThreads = 512;
-constexpr int kFwdBlockM = 256;  // query rows per workgroup (32 per wave)
-constexpr int kFwdBlockN = 64;   // keys per staged tile
+constexpr int kFwdBlockN = 64;   // keys per staged tile (threads and query rows per workgroup follow from WAVES, see the kernel)
 
 // WAVES = 8: the original 512-thread / 256-row workgroup, one per CU.  WAVES = 4 ("simple4"): 256 threads / 128 rows, TWO workgroups
 // per CU (64 KB LDS and <= 256 registers each): the two independent workgroups on a CU decorrelate on their own, which is what
@@ -325,6 +323,7 @@ static hipError_t launch_fwd_t(const FwdKernelParams& kp, hipStream_t stream) {
 }
 template <int WAVES>
 static hipError_t launch_fwd_w(FwdKernelParams kp, int dtype, hipStream_t stream) {
+    kp.varlen_slots = 0;   // bisecting schedules keep the plain varlen grid
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + 32 * WAVES - 1) / (32 * WAVES));
     if (dtype == 0) {
         return kp.d == 128 ? launch_fwd_t<_Float16, 128, WAVES>(kp, stream) : launch_fwd_t<_Float16, 64, WAVES>(kp, stream);

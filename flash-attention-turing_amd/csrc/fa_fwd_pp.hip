@@ -46,10 +46,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;
 
-    uint32_t tile, bh;
-    decode_block(blockIdx.x, p.n_q_tiles, (uint32_t)(p.b * p.h), tile, bh);
-    if (CAUSAL) tile = p.n_q_tiles - 1 - tile;
-    const int batch = bh / p.h, head = bh % p.h, head_k = head / p.h_ratio;
+    int tile, batch, head, tiles_seq;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (CAUSAL) tile = tiles_seq - 1 - tile;      // heaviest (latest) query tiles first
+    const int head_k = head / p.h_ratio;
 
     int sq = p.seqlen_q, sk = p.seqlen_k;
     int64_t q_row0 = 0, k_row0 = 0;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 
 template <typename T, int D>
 static hipError_t launch_pp_t(const FwdKernelParams& kp, hipStream_t stream) {
-    const uint32_t grid = kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
+    const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     if (grid == 0) return hipSuccess;
     if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
     else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
@@ -384,6 +384,7 @@ static hipError_t launch_pp_t(const FwdKernelParams& kp, hipStream_t stream) {
 
 hipError_t launch_fwd_pp(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
+    kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, stream) : launch_pp_t<_Float16, 64>(kp, stream);
     return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, stream) : launch_pp_t<__bf16, 64>(kp, stream);
 }

@@ -311,6 +311,7 @@ static hipError_t launch_sp_t(const FwdKernelParams& kp, hipStream_t stream) {
 }
 
 hipError_t launch_fwd_sp(FwdKernelParams kp, int dtype, hipStream_t stream) {
+    kp.varlen_slots = 0;   // plain varlen grid
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kSpBlockM - 1) / kSpBlockM);
     if (dtype == 0) return kp.d == 128 ? launch_sp_t<_Float16, 128>(kp, stream) : launch_sp_t<_Float16, 64>(kp, stream);
     return kp.d == 128 ? launch_sp_t<__bf16, 128>(kp, stream) : launch_sp_t<__bf16, 64>(kp, stream);

@@ -25,6 +25,8 @@ struct FwdKernelParams {
     int32_t b, seqlen_q, seqlen_k, h, h_k, h_ratio, d;
     int32_t is_causal;
     uint32_t n_q_tiles;         // filled by the launcher
+    uint32_t varlen_slots;      // filled by the launcher: != 0 -> compact varlen grid (fa_device.hpp), 0 -> plain grid
+    int64_t total_q;            // packed token count of q (0 = unknown)
     float scale_log2e;          // log2(e) / sqrt(d)
     float scale;                // 1 / sqrt(d)
 };
@@ -47,6 +49,8 @@ struct BwdKernelParams {
     int32_t b, seqlen_q, seqlen_k, h, h_k, h_ratio, d;
     int32_t is_causal;
     uint32_t n_q_tiles, n_k_tiles;
+    uint32_t varlen_slots;      // per launch, like FwdKernelParams
+    int64_t total_q, total_k;   // packed token counts (0 = unknown)
     float scale_log2e;
     float scale;
 };

@@ -170,6 +170,7 @@ std::vector<at::Tensor> mha_varlen_fwd(at::Tensor q, at::Tensor k, at::Tensor v,
     p.h = (int32_t)num_heads; p.h_k = (int32_t)num_heads_k; p.d = (int32_t)head_size;
     p.dtype = fa_dtype_of(q); p.is_causal = is_causal;
     p.q_stride = strides3(q); p.k_stride = strides3(k); p.v_stride = strides3(v); p.o_stride = strides3(out);
+    p.total_q = q.size(0); p.total_k = k.size(0);   // packed row counts >= cu_seqlens[b]: lets the library size the grid by tokens present
     check_status(fa_run_mha_fwd(&p, current_stream(q)));
     return {out, l};
 }
@@ -216,6 +217,7 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     p.dtype = fa_dtype_of(q); p.is_causal = is_causal;
     p.q_stride = strides3(q); p.k_stride = strides3(k); p.v_stride = strides3(v); p.o_stride = strides3(out);
     p.do_stride = strides3(dout); p.dq_stride = strides3(dq); p.dk_stride = strides3(dk); p.dv_stride = strides3(dv);
+    p.total_q = q.size(0); p.total_k = k.size(0);
     check_status(fa_run_mha_bwd(&p, current_stream(q)));
     return {dq, dk, dv};
 }

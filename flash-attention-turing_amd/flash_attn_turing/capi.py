@@ -29,7 +29,8 @@ class FwdParams(ctypes.Structure):
                 ("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp),
                 ("b", _i32), ("seqlen_q", _i32), ("seqlen_k", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
                 ("dtype", _i32), ("is_causal", _i32),
-                ("q_stride", Strides), ("k_stride", Strides), ("v_stride", Strides), ("o_stride", Strides)]
+                ("q_stride", Strides), ("k_stride", Strides), ("v_stride", Strides), ("o_stride", Strides),
+                ("total_q", ctypes.c_int64), ("total_k", ctypes.c_int64)]      # ABI 2, optional (0 = unknown)
 
 
 class BwdParams(ctypes.Structure):
@@ -39,7 +40,8 @@ class BwdParams(ctypes.Structure):
                 ("b", _i32), ("seqlen_q", _i32), ("seqlen_k", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
                 ("dtype", _i32), ("is_causal", _i32),
                 ("q_stride", Strides), ("k_stride", Strides), ("v_stride", Strides), ("o_stride", Strides),
-                ("do_stride", Strides), ("dq_stride", Strides), ("dk_stride", Strides), ("dv_stride", Strides)]
+                ("do_stride", Strides), ("dq_stride", Strides), ("dk_stride", Strides), ("dv_stride", Strides),
+                ("total_q", ctypes.c_int64), ("total_k", ctypes.c_int64)]
 
 
 _lib = None

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 1
+#define FA_ABI_VERSION 2   /* 2: optional total_q / total_k appended to fa_fwd_params / fa_bwd_params */
 
 enum fa_dtype { FA_FP16 = 0, FA_BF16 = 1 };
 
@@ -86,6 +86,12 @@ typedef struct fa_fwd_params {
     int32_t dtype;              /* enum fa_dtype */
     int32_t is_causal;
     fa_strides q_stride, k_stride, v_stride, o_stride;
+    /* ABI 2, optional (0 = unknown).  varlen only: number of rows of the PACKED q / k tensors (what the reference's mha_varlen_fwd
+     * sees as q.size(0) / k.size(0), flash_api.cpp:319-381).  MUST be >= cu_seqlens_q[b] / cu_seqlens_k[b] (like max_seqlen, the
+     * library cannot check device values without synchronising).  When given, the launch grid is sized by the tokens actually
+     * present instead of max_seqlen x batch, which matters for batches of very unequal lengths (varlen). */
+    int64_t total_q;
+    int64_t total_k;
 } fa_fwd_params;
 
 /* Mirrors Flash_bwd_params (reference src/flash.h:55-76). */
@@ -111,6 +117,8 @@ typedef struct fa_bwd_params {
     int32_t dtype;
     int32_t is_causal;
     fa_strides q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
+    int64_t total_q;            /* ABI 2, optional, see fa_fwd_params */
+    int64_t total_k;
 } fa_bwd_params;
 
 /* ---- library info ---------------------------------------------------------------------- */

@@ -53,7 +53,10 @@ def analyse(hip_source, extra_flags=()):
         if name + ":" not in txt:
             continue
         body = txt[txt.index(name + ":"):]
-        body = body[:body.index("s_endpgm")]
+        # the function's extent is its .Lfunc_end label (an early `return` compiles to an early s_endpgm: cutting at the first
+        # s_endpgm once truncated every dK/dV kernel to its prologue and made the loop checks pass vacuously)
+        m = re.search(r"^\.Lfunc_end\d+:", body, re.M)
+        body = body[:m.start()] if m else body[:body.rindex("s_endpgm")]
         info["mfma_total"] = len(re.findall(r"v_mfma", body))
         info["loops"] = []
         for lab, seg in _loops(body):

@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/flash_attn_gfx950.h but not exported"
-    assert L.fa_abi_version() == 1
+    assert L.fa_abi_version() == 2
     assert b"gfx950" in L.fa_build_info()
 
 
@@ -54,9 +54,16 @@ def test_host_validation_error_codes_without_gpu():
     p.q = p.k = p.v = p.o = p.lse = addr
     p.q_stride = p.k_stride = p.v_stride = p.o_stride = capi.Strides(8 * 2 * 128, 2 * 128 + 4, 128)
     assert L.fa_run_mha_fwd(ctypes.byref(p), None) == capi.FA_ERR_BAD_STRIDE
+    # ABI 2: the optional packed-token totals must be >= 0 (0 = unknown); rejected before any launch
+    p.q_stride = p.k_stride = p.v_stride = p.o_stride = capi.Strides(8 * 2 * 128, 2 * 128, 128)
+    p.total_q = -1
+    assert L.fa_run_mha_fwd(ctypes.byref(p), None) == capi.FA_ERR_BAD_SHAPE
+    assert "total_q" in capi.last_error()
 
 
 def test_struct_layout_matches_header():
-    # 7 pointers + 8 int32 + 4 x 3 int64 ; 12 pointers + 8 int32 + 8 x 3 int64
-    assert ctypes.sizeof(capi.FwdParams) == 7 * 8 + 8 * 4 + 4 * 24
-    assert ctypes.sizeof(capi.BwdParams) == 12 * 8 + 8 * 4 + 8 * 24
+    # 7 pointers + 8 int32 + 4 x 3 int64 + 2 int64 (ABI 2: total_q, total_k) ; 12 pointers + 8 int32 + 8 x 3 int64 + 2 int64
+    assert ctypes.sizeof(capi.FwdParams) == 7 * 8 + 8 * 4 + 4 * 24 + 16
+    assert ctypes.sizeof(capi.BwdParams) == 12 * 8 + 8 * 4 + 8 * 24 + 16
+    # the ABI 1 prefix is unchanged: the appended fields sit at the very end
+    assert capi.FwdParams.total_q.offset == 7 * 8 + 8 * 4 + 4 * 24 and capi.BwdParams.total_q.offset == 12 * 8 + 8 * 4 + 8 * 24

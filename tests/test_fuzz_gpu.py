@@ -231,3 +231,48 @@ def test_strided_views_are_bit_identical_to_contiguous(gpu, case):
         for g, r, tname in zip(got, ref, ("O", "LSE", "dQ", "dK", "dV")):
             assert torch.equal(g, r), f"{tname} differs for layout '{name}' [case {case}: b{b} sq{s_q} sk{s_k} h{h}/{hk} d{d} {dt} causal={causal}] " \
                                       f"max|diff| {(g.float() - r.float()).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case):
+    """fa_*_params.total_q / total_k only change WHICH workgroup computes a tile (grid sized by the tokens present instead of
+    max_seqlen x batch, fa_device.hpp): results through the param-struct entry points must not change by a bit, skewed batches with
+    empty sequences included; with totals unset the same call uses the plain grid."""
+    import ctypes
+
+    from flash_attn_turing import capi
+
+    rng = np.random.default_rng(5000 + case)
+    lens = [int(rng.choice([1500, 2600, 4100]))] + [int(rng.choice([0, 1, 17, 64, 130, 300])) for _ in range(int(rng.integers(5, 40)))]
+    rng.shuffle(lens)
+    h, hk = _heads(rng)
+    d = int(rng.choice([64, 128]))
+    dt = ("fp16", "bf16")[case % 2]
+    causal = bool(case % 3 == 0)
+    tdt = U.torch_dtype(dt)
+    tot, b, mx = sum(lens), len(lens), max(lens)
+    gen = torch.Generator(device="cpu").manual_seed(15000 + case)
+    q, do = (torch.randn(tot, h, d, generator=gen).to(gpu, tdt) for _ in range(2))
+    k, v = (torch.randn(tot, hk, d, generator=gen).to(gpu, tdt) for _ in range(2))
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(gpu)
+    L = capi.lib()
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    row = lambda t: capi.Strides(0, t.stride(0), t.stride(1))
+    res = {}
+    for total in (0, tot, tot + 1000):          # unknown -> plain grid; exact; an upper bound (slack slots must exit cleanly)
+        o, dq, dk, dv = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        lse = torch.zeros(b, h, mx, device=gpu, dtype=torch.float32)
+        dsum = torch.zeros_like(lse)
+        common = dict(q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=o.data_ptr(), lse=lse.data_ptr(), cu_seqlens_q=cu.data_ptr(), cu_seqlens_k=cu.data_ptr(),
+                      b=b, seqlen_q=mx, seqlen_k=mx, h=h, h_k=hk, d=d, dtype=capi.dtype_code(tdt), is_causal=int(causal),
+                      q_stride=row(q), k_stride=row(k), v_stride=row(v), o_stride=row(o), total_q=total, total_k=total)
+        fp = capi.FwdParams(**common)
+        bp = capi.BwdParams(dout=do.data_ptr(), dq=dq.data_ptr(), dk=dk.data_ptr(), dv=dv.data_ptr(), dsoftmax_sum=dsum.data_ptr(),
+                            do_stride=row(do), dq_stride=row(dq), dk_stride=row(dk), dv_stride=row(dv), **common)
+        capi.check(L.fa_run_mha_fwd(ctypes.byref(fp), st))
+        capi.check(L.fa_run_mha_bwd(ctypes.byref(bp), st))
+        torch.cuda.synchronize()
+        res[total] = (o, lse, dq, dk, dv)
+    for total in (tot, tot + 1000):
+        for g, r, name in zip(res[total], res[0], ("O", "LSE", "dQ", "dK", "dV")):
+            assert torch.equal(g, r), f"{name} differs between compact (total={total}) and plain grid [case {case}: lens {lens} h{h}/{hk} d{d} {dt} causal={causal}]"

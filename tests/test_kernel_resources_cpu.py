@@ -31,6 +31,9 @@ def test_every_kernel_was_analysed(kernels):
     assert len(kernels) >= 36 and len(with_loops) >= 32, (len(kernels), len(with_loops))
     for (f, name), info in kernels.items():
         assert {"vgprs", "agprs", "scratch_bytes", "occupancy"} <= set(info), (f, name, info)
+        # no vacuous passes: every MFMA kernel must have been seen WITH its MFMAs and at least one MFMA loop
+        if "dot_do_o" not in name:
+            assert info.get("mfma_total", 0) >= 16 and info.get("loops"), (f, name, info.get("mfma_total"), info.get("loops"))
 
 
 def test_no_spills_or_accumulator_shuffles_inside_mfma_loops(kernels):
