@@ -233,7 +233,7 @@ def test_strided_views_are_bit_identical_to_contiguous(gpu, case):
                                       f"max|diff| {(g.float() - r.float()).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(11))
 def test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case):
     """fa_*_params.total_q / total_k only change WHICH workgroup computes a tile (grid sized by the tokens present instead of
     max_seqlen x batch, fa_device.hpp): results through the param-struct entry points must not change by a bit, skewed batches with
@@ -243,7 +243,13 @@ def test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case):
     from flash_attn_turing import capi
 
     rng = np.random.default_rng(5000 + case)
-    lens = [int(rng.choice([1500, 2600, 4100]))] + [int(rng.choice([0, 1, 17, 64, 130, 300])) for _ in range(int(rng.integers(5, 40)))]
+    if case < 6:
+        lens = [int(rng.choice([1500, 2600, 4100]))] + [int(rng.choice([0, 1, 17, 64, 130, 300])) for _ in range(int(rng.integers(5, 40)))]
+    else:
+        # more than 64 sequences: every lane of the slot lookup owns SEVERAL sequences (2 at 70-128, 3 at 130, 5 at 300, 8 at 512);
+        # 513 is past the lookup's capacity and must fall back to the plain grid
+        nseq = {6: 70, 7: 130, 8: 300, 9: 512, 10: 513}[case]
+        lens = [int(rng.choice([700, 1300]))] + [int(rng.choice([0, 1, 5, 33, 64, 100])) for _ in range(nseq - 1)]
     rng.shuffle(lens)
     h, hk = _heads(rng)
     d = int(rng.choice([64, 128]))
