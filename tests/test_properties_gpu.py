@@ -234,3 +234,72 @@ def test_large_magnitude_inputs_stay_finite(gpu):
         assert torch.isfinite(o).all() and torch.isfinite(lse).all()
         U.assert_close(o.float().cpu().numpy(), o_r.cpu().numpy(), "fp16", "O large", scale=2.0)
         assert ((lse - lse_r).abs() / lse_r.abs().clamp_min(1.0)).max().item() <= 1e-4
+
+
+def test_launch_path_is_hip_graph_capturable(gpu):
+    """The C ABI promises no allocation, no synchronisation and no host-dependent state at launch (include/flash_attn_gfx950.h), so
+    forward + backward must be capturable in a HIP graph and replay to the same bits - dense and varlen (compact grid: the slot lookup
+    reads cu_seqlens on the device, nothing on the host)."""
+    import ctypes
+
+    from flash_attn_turing import capi
+
+    L = capi.lib()
+    b, s, h, hk, d, dt = 3, 300, 4, 2, 128, torch.float16
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    q, do = (torch.randn(b, s, h, d, generator=gen).to(gpu, dt) for _ in range(2))
+    k, v = (torch.randn(b, s, hk, d, generator=gen).to(gpu, dt) for _ in range(2))
+    o, dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lse = torch.empty(b, h, s, device=gpu, dtype=torch.float32)
+    dsum = torch.empty_like(lse)
+
+    def dense(stream):
+        capi.mha_fwd(q, k, v, o, lse, True, stream=stream)
+        capi.mha_bwd(q, k, v, o, lse, do, dq, dk, dv, dsum, True, stream=stream)
+
+    # varlen through the param structs with totals set -> compact grid
+    lens = [700, 0, 33, 64, 1]
+    tot, nb, mx = sum(lens), len(lens), max(lens)
+    qv, dov = (torch.randn(tot, h, d, generator=gen).to(gpu, dt) for _ in range(2))
+    kv, vv = (torch.randn(tot, hk, d, generator=gen).to(gpu, dt) for _ in range(2))
+    ov, dqv, dkv, dvv = torch.zeros_like(qv), torch.zeros_like(qv), torch.zeros_like(kv), torch.zeros_like(vv)
+    lsev = torch.zeros(nb, h, mx, device=gpu, dtype=torch.float32)
+    dsv = torch.zeros_like(lsev)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(gpu)
+    row = lambda t: capi.Strides(0, t.stride(0), t.stride(1))
+    common = dict(q=qv.data_ptr(), k=kv.data_ptr(), v=vv.data_ptr(), o=ov.data_ptr(), lse=lsev.data_ptr(), cu_seqlens_q=cu.data_ptr(), cu_seqlens_k=cu.data_ptr(),
+                  b=nb, seqlen_q=mx, seqlen_k=mx, h=h, h_k=hk, d=d, dtype=capi.dtype_code(dt), is_causal=0,
+                  q_stride=row(qv), k_stride=row(kv), v_stride=row(vv), o_stride=row(ov), total_q=tot, total_k=tot)
+    fp = capi.FwdParams(**common)
+    bp = capi.BwdParams(dout=dov.data_ptr(), dq=dqv.data_ptr(), dk=dkv.data_ptr(), dv=dvv.data_ptr(), dsoftmax_sum=dsv.data_ptr(),
+                        do_stride=row(dov), dq_stride=row(dqv), dk_stride=row(dkv), dv_stride=row(dvv), **common)
+
+    def varlen(stream):
+        capi.check(L.fa_run_mha_fwd(ctypes.byref(fp), stream))
+        capi.check(L.fa_run_mha_bwd(ctypes.byref(bp), stream))
+
+    outs = (o, lse, dq, dk, dv, ov, lsev, dqv, dkv, dvv)
+    cur = torch.cuda.current_stream(gpu).cuda_stream
+    dense(cur); varlen(cur)                       # eager reference run (also warms up lazy init before capture)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in outs]
+    for t in outs:
+        if t is lsev:
+            t.zero_()        # padded varlen LSE entries are never written (the host module zero-fills them); valid entries are non-zero in ref
+        elif t.dtype == torch.float32:
+            t.fill_(123.0)
+        else:
+            t.fill_(float("nan"))
+    assert not torch.equal(lsev, ref[6])
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            dense(side.cuda_stream); varlen(side.cuda_stream)
+    torch.cuda.synchronize()
+    for rep in range(2):                           # nothing ran during capture; replay twice
+        graph.replay()
+        torch.cuda.synchronize()
+        for name, g, r in zip(("O", "LSE", "dQ", "dK", "dV", "O varlen", "LSE varlen", "dQ varlen", "dK varlen", "dV varlen"), outs, ref):
+            assert torch.equal(g, r), f"{name} differs after graph replay {rep}"
