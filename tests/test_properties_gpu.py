@@ -303,3 +303,59 @@ def test_launch_path_is_hip_graph_capturable(gpu):
         torch.cuda.synchronize()
         for name, g, r in zip(("O", "LSE", "dQ", "dK", "dV", "O varlen", "LSE varlen", "dQ varlen", "dK varlen", "dV varlen"), outs, ref):
             assert torch.equal(g, r), f"{name} differs after graph replay {rep}"
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_identity_inputs_analytic_known_answer(gpu, d, causal):
+    """Analytic known-answer test on the HIP kernels, independent of every reference implementation (the reference's identity-input
+    debug mode, test_flash_attn.py:74-109: q and k one-hot with index row % d): s_ij = 1/sqrt(d) where (i - j) % d == 0 else 0, so
+    P, O = P V and LSE have closed forms.  Dense and varlen (the packed batch restarts the index at every sequence), lengths above d
+    so that the index wraps, sq != sk with the bottom-right causal alignment."""
+    import flash_attn_turing as F
+
+    h, hk = 4, 2
+    rng = np.random.default_rng(31 + d)
+
+    def onehot(n):
+        t = np.zeros((n, d), np.float32)
+        t[np.arange(n), np.arange(n) % d] = 1.0
+        return t
+
+    def expect(sq, sk, v):            # v: (sk, hk, d) float32 -> O (sq, h, d), LSE (h, sq) in float64
+        i, j = np.arange(sq)[:, None], np.arange(sk)[None, :]
+        s = np.where((i - j) % d == 0, 1.0 / np.sqrt(d), 0.0)
+        if causal:
+            s = np.where(j - i > sk - sq, -np.inf, s)
+        m = s.max(-1, keepdims=True)
+        dead = ~np.isfinite(m[:, 0])
+        e = np.exp(s - np.where(np.isfinite(m), m, 0.0))
+        l = e.sum(-1)
+        p = np.where(dead[:, None], 0.0, e / np.where(l > 0, l, 1.0)[:, None])
+        lse = np.where(dead, 0.0, np.log(np.where(l > 0, l, 1.0)) + np.where(np.isfinite(m[:, 0]), m[:, 0], 0.0))
+        vv = np.repeat(v.astype(np.float64), h // hk, axis=1)           # (sk, h, d)
+        return np.einsum("ij,jhd->ihd", p, vv), np.broadcast_to(lse, (h, sq))
+
+    shapes = [(96, 96), (300, 300), (200, 333), (333, 200)]
+    # dense, one shape at a time
+    for sq, sk in shapes:
+        q = torch.from_numpy(np.broadcast_to(onehot(sq)[None, :, None, :], (1, sq, h, d)).copy()).to(gpu, torch.float16)
+        k = torch.from_numpy(np.broadcast_to(onehot(sk)[None, :, None, :], (1, sk, hk, d)).copy()).to(gpu, torch.float16)
+        vn = rng.standard_normal((sk, hk, d)).astype(np.float16).astype(np.float32)
+        v = torch.from_numpy(vn[None]).to(gpu, torch.float16)
+        o, lse = F.fwd(q, k, v, causal)
+        eo, el = expect(sq, sk, vn)
+        U.assert_close(o[0].float().cpu().numpy(), eo, "fp16", f"O identity dense sq={sq} sk={sk}")
+        assert np.abs(lse[0].cpu().numpy() - el).max() <= U.LSE_TOL, (sq, sk)
+    # the same four problems as ONE packed varlen batch
+    lq, lk = [s[0] for s in shapes], [s[1] for s in shapes]
+    cu_q = np.concatenate([[0], np.cumsum(lq)]).astype(np.int32); cu_k = np.concatenate([[0], np.cumsum(lk)]).astype(np.int32)
+    qn = np.concatenate([np.broadcast_to(onehot(n)[:, None, :], (n, h, d)) for n in lq])
+    kn = np.concatenate([np.broadcast_to(onehot(n)[:, None, :], (n, hk, d)) for n in lk])
+    vn = rng.standard_normal((int(cu_k[-1]), hk, d)).astype(np.float16).astype(np.float32)
+    q, k, v = (torch.from_numpy(np.ascontiguousarray(x)).to(gpu, torch.float16) for x in (qn, kn, vn))
+    o, lse = F.varlen_fwd(q, k, v, torch.from_numpy(cu_q).to(gpu), torch.from_numpy(cu_k).to(gpu), max(lq), max(lk), causal)
+    for i, (sq, sk) in enumerate(shapes):
+        eo, el = expect(sq, sk, vn[cu_k[i]:cu_k[i + 1]])
+        U.assert_close(o[cu_q[i]:cu_q[i + 1]].float().cpu().numpy(), eo, "fp16", f"O identity varlen seq {i}")
+        assert np.abs(lse[i, :, :sq].cpu().numpy() - el).max() <= U.LSE_TOL, ("varlen", i)
