@@ -20,20 +20,6 @@
 #include "fa_device.hpp"
 #include "fa_params.hpp"
 
-// FA_ABL_KV: TIMING-ONLY ablations of fa_bwd_dkdv_kernel for tools/ab_bwd.py (results are WRONG when non-zero; build.py never
-// defines it).  bit0: the loop-invariant K / V fragments are read from LDS once per tile instead of once per MFMA;
-// bit1: same for the Q / dO row fragments; bit2: one transposed-read pair per d-block instead of one per MFMA;
-// bit3: no workgroup barrier at the end of a tile (the DMA wait stays); bit4: that barrier (and the DMA wait) sits between the
-// S and dP MFMAs of the tile instead of at its end (the structure of a 3-deep-Q-ring design, timed on the racy 2-deep ring).
-#ifndef FA_ABL_KV
-#define FA_ABL_KV 0
-#endif
-// FA_ABL_DQ: the same for fa_bwd_dq_kernel.  bit0: no workgroup barrier per tile; bit1: no exp / dS arithmetic (dS := S);
-// bit2: K / V row fragments and K^T transposed fragments read for every other MFMA only.
-#ifndef FA_ABL_DQ
-#define FA_ABL_DQ 0
-#endif
-
 namespace fa {
 
 // =============================================================================================
@@ -57,7 +43,7 @@ __global__ __launch_bounds__(kDotThreads) void fa_bwd_dot_do_o_kernel(const BwdK
     int64_t row0 = 0, o_boff = (int64_t)batch * p.o.batch, do_boff = (int64_t)batch * p.dout.batch;
     if (p.cu_seqlens_q != nullptr) {
         const int beg = p.cu_seqlens_q[batch];
-        sq = p.cu_seqlens_q[batch + 1] - beg;
+        sq = min(p.cu_seqlens_q[batch + 1] - beg, p.seqlen_q);   // D rows are padded to max_seqlen_q: never write past them
         row0 = beg;
         o_boff = do_boff = 0;
     }
@@ -122,7 +108,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
             do_boff = (int64_t)batch * p.dout.batch, dq_boff = (int64_t)batch * p.dq.batch;
     if (p.cu_seqlens_q != nullptr) {
         const int qb = p.cu_seqlens_q[batch], kb = p.cu_seqlens_k[batch];
-        sq = p.cu_seqlens_q[batch + 1] - qb;
+        sq = min(p.cu_seqlens_q[batch + 1] - qb, p.seqlen_q);   // clamp to the declared max_seqlen_q (padded LSE / D rows)
         sk = p.cu_seqlens_k[batch + 1] - kb;
         q_row0 = qb; k_row0 = kb;
         q_boff = k_boff = v_boff = do_boff = dq_boff = 0;
@@ -221,9 +207,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
         const int n0 = t * kDqBlockN;
         FA_LDS char* kbuf = smem + (t & 1) * TILEB;
         FA_LDS char* vbuf = smem + 2 * TILEB + (t & 1) * TILEB;
-#if !(FA_ABL_DQ & 1)
         __syncthreads();      // tile t is in LDS (every wave waited for its pieces); buffer (t+1)&1 is free again
-#endif
         if (t + 1 < n_tiles) dma_tiles(t + 1, (t + 1) & 1);
         const bool wave_active = !CAUSAL || (n0 <= wave_q_hi + delta);
         if (wave_active) {
@@ -239,41 +223,24 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi) {           // two 32-key halves, keeps S/dP at 16+16 regs
                 f32x16 sacc, dpacc;
-#if FA_ABL_DQ & 4
-                u32x4 abl_f = {0, 0, 0, 0};
-#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-#if FA_ABL_DQ & 4
-                    if ((ks & 1) == 0) abl_f = lds_read16(kbuf, row_rd[ks] + bi * 32 * ROWB);
-                    const u32x4 kf = abl_f;
-#else
                     const u32x4 kf = lds_read16(kbuf, row_rd[ks] + bi * 32 * ROWB);
-#endif
                     sacc = LP<T>::mfma(kf, qf[ks], sacc);          // S^T = K Q^T
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-#if FA_ABL_DQ & 4
-                    if ((ks & 1) == 0) abl_f = lds_read16(vbuf, row_rd[ks] + bi * 32 * ROWB);
-                    const u32x4 vf = abl_f;
-#else
                     const u32x4 vf = lds_read16(vbuf, row_rd[ks] + bi * 32 * ROWB);
-#endif
                     dpacc = LP<T>::mfma(vf, dof[ks], dpacc);       // dP^T = V dO^T
                 }
                 // P = exp(s*scale - LSE) (flash_bwd_kernel.h:474), dS = P * (dP - D) (:490)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-#if FA_ABL_DQ & 2
-                    sacc[r] = sacc[r] + dpacc[r];
-#else
                     float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -lse2));
                     pv = (32 * bi + (r & 3) + 8 * (r >> 2)) <= lim_loc ? pv : 0.f;
                     sacc[r] = pv * (dpacc[r] - dsum);
-#endif
                 }
                 // dQ^T (D x 32 queries) += K^T (D x 32 keys) * dS^T (32 keys x 32 queries)
 #pragma unroll
@@ -282,18 +249,9 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
                     const int ts = 2 * bi + half;
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
-#if FA_ABL_DQ & 4
-                        if ((db & 1) == 0) {
-                            const u32x2 a0 = lds_read_tr8(kbuf, tr_rd[0][db] + ts * 16 * ROWB);
-                            const u32x2 a1 = lds_read_tr8(kbuf, tr_rd[1][db] + ts * 16 * ROWB);
-                            abl_f = u32x4{a0.x, a0.y, a1.x, a1.y};
-                        }
-                        const u32x4 ktf = abl_f;
-#else
                         const u32x2 a0 = lds_read_tr8(kbuf, tr_rd[0][db] + ts * 16 * ROWB);
                         const u32x2 a1 = lds_read_tr8(kbuf, tr_rd[1][db] + ts * 16 * ROWB);
                         const u32x4 ktf = {a0.x, a0.y, a1.x, a1.y};
-#endif
                         dqacc[db] = LP<T>::mfma(ktf, dsf, dqacc[db]);
                     }
                 }
@@ -367,7 +325,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             do_boff = (int64_t)batch * p.dout.batch, dk_boff = (int64_t)batch * p.dk.batch, dv_boff = (int64_t)batch * p.dv.batch;
     if (p.cu_seqlens_q != nullptr) {
         const int qb = p.cu_seqlens_q[batch], kb = p.cu_seqlens_k[batch];
-        sq = p.cu_seqlens_q[batch + 1] - qb;
+        sq = min(p.cu_seqlens_q[batch + 1] - qb, p.seqlen_q);   // clamp to the declared max_seqlen_q (padded LSE / D rows)
         sk = p.cu_seqlens_k[batch + 1] - kb;
         q_row0 = qb; k_row0 = kb;
         q_boff = k_boff = v_boff = do_boff = dk_boff = dv_boff = 0;
@@ -509,46 +467,18 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             const bool need_mask = CAUSAL && (wave_k_hi > mh + delta);
             const int thr = need_mask ? (n0 + key_row) - (mh + 4 * hi + delta) : (int)0x80000000;
             f32x16 sacc, dpacc;
-#if FA_ABL_KV
-            u32x4 abl_a = {0, 0, 0, 0}, abl_b = {0, 0, 0, 0}, abl_t[DB];
-            (void)abl_a; (void)abl_b; (void)abl_t;
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-#if FA_ABL_KV & 2
-                if (ks == 0) abl_a = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
-                const u32x4 qa = abl_a;
-#else
                 const u32x4 qa = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
-#endif
-#if FA_ABL_KV & 1
-                if (ks == 0) abl_b = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
-                const u32x4 kf = abl_b;
-#else
                 const u32x4 kf = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
-#endif
                 sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
             }
-#if FA_ABL_KV & 16
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#endif
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-#if FA_ABL_KV & 2
-                if (ks == 0) abl_a = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
-                const u32x4 da = abl_a;
-#else
                 const u32x4 da = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
-#endif
-#if FA_ABL_KV & 1
-                if (ks == 0) abl_b = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
-                const u32x4 vf = abl_b;
-#else
                 const u32x4 vf = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
-#endif
                 dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
             }
             f32x16 pacc;
@@ -574,16 +504,6 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 const int ts = 2 * qh + half;                       // 16-row k-slice of the 64-row tile
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-#if FA_ABL_KV & 4
-                    if (half == 0) {
-                        const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
-                        const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
-                        abl_t[db] = u32x4{a0.x, a0.y, a1.x, a1.y};
-                    }
-                    const u32x4 dot = abl_t[db];
-                    LP<T>::mfma_agpr(dvacc[db], dot, pf);
-                    LP<T>::mfma_agpr(dkacc[db], dot, dsf);
-#else
                     const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
                     const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
                     const u32x4 dot = {a0.x, a0.y, a1.x, a1.y};
@@ -592,20 +512,21 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                     const u32x2 b1 = lds_read_tr8(qbuf, tr_rd[1][db] + ts * 16 * ROWB);
                     const u32x4 qt = {b0.x, b0.y, b1.x, b1.y};
                     LP<T>::mfma_agpr(dkacc[db], qt, dsf);           // dK^T += Q^T dS    (AGPR accumulator)
-#endif
                 }
             }
         }
         if (more) land_stats(buf ^ 1);
-#if !(FA_ABL_KV & 16)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces have landed
-#endif
-#if !(FA_ABL_KV & (8 | 16))
         __syncthreads();
-#endif
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------
+    // The accumulators were last written by MFMAs issued from inline asm, which the hazard recogniser does not see:
+    // an 8-pass XDL write needs 11+ wait states before a VALU (v_accvgpr_read) may read it.  Pad explicitly, and tie
+    // every accumulator to a statement after the pad so no read can be scheduled above it.
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { asm volatile("" : "+a"(dkacc[db])); asm volatile("" : "+a"(dvacc[db])); }
     // (the loop's last barrier has passed: K/V tiles, rings and stats are dead, LDS is scratch)
     // 1) the qh = 1 waves hand their partial sums to their qh = 0 partner through LDS (fp32,
     //    [key block][register][lane], conflict-free); 2) the partner adds, applies the softmax

@@ -62,8 +62,6 @@ extern "C" {
 
 int fa_abi_version(void) { return FA_ABI_VERSION; }
 const char* fa_last_error(void) { return g_err; }
-/* debug / A-B timing hook, not part of the public header: selects the forward schedule */
-void fa_debug_set_fwd_impl(int impl) { fa::set_fwd_impl(impl); }
 
 #define FA_STR2(x) #x
 #define FA_STR(x) FA_STR2(x)

@@ -135,8 +135,9 @@ FA_DEV uint32_t lds_tile_logical_slot(uint32_t row, uint32_t phys) {
 
 // Asynchronous HBM -> LDS copy (buffer_load_dwordx4 ... lds): every lane moves 16 bytes from
 // rsrc[voffset] to lds_base + 16 * lane (wave-uniform base, lane-linear image); out-of-range
-// source addresses write zeros.  Completion is tracked by vmcnt; hipcc drains it at the next
-// __syncthreads().
+// source addresses write zeros.  Completion is tracked by vmcnt.  gfx950 has the back-off barrier, so
+// nothing obliges hipcc to drain vmcnt before s_barrier: callers wait explicitly (s_waitcnt vmcnt(0))
+// before the barrier that publishes the data to the other waves.
 FA_DEV void dma16_to_lds(rsrc_t r, uint32_t voffset, FA_LDS char* lds_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (FA_LDS void*)lds_base, 16, voffset, 0, 0, 0);
 }
@@ -161,8 +162,12 @@ FA_DEV uint32_t lds_addr(const FA_LDS char* p) { return (uint32_t)(uintptr_t)p; 
 FA_DEV void dma16_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds_byte_addr) {
     // s_nop 4: SGPRs of the descriptor / M0 source may have just been written by v_readfirstlane
     // or SALU; s_nop 0 after the M0 write (hazard tables 11 / 38).
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :: "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
+    // M0 is compiler-reserved (the compiler-visible LDS-DMA builtin addresses LDS through it too) and an
+    // "m0" clobber is not honoured for reserved registers, so the statement saves and restores it: a kernel
+    // may mix this with dma16_to_lds() without relying on where hipcc happens to re-materialise M0.
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
 }
 
 FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }

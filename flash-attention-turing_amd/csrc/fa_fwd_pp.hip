@@ -1,8 +1,28 @@
-// fa_fwd_pp.hip — the shipped forward schedule: two-group ping-pong (matrix phase of one wave group
-// against the softmax phase of the other).  Tiling, fragment layouts and the LDS image are the
-// ones documented in fa_fwd.hip / fa_device.hpp; measured against the alternatives with
-// tools/fwd_ab.py (MI355X, b4 h32 d128: 1.09-1.17 PFLOP/s vs 1.02-1.11 for fa_fwd_sp.hip and
-// 0.82-0.89 for the baseline schedule).
+// fa_fwd_pp.hip — fused attention forward for MI355X (gfx950, CDNA4): two-group ping-pong schedule.
+//
+// Replaces the reference's flash_fwd_kernel / compute_attn_1rowblock
+// (csrc/flash_attn/src/flash_fwd_kernel.h:23-789, launch flash_fwd_launch_template.h:45-86)
+// with a from-scratch wave64 / MFMA 32x32x16 design:
+//
+//   * workgroup = 8 waves (512 threads) = one 256-row Q tile of one (batch, head);
+//     each wave owns 32 query rows for the whole K loop (Q fragments live in VGPRs).
+//   * K/V tiles of 64 keys arrive by LDS-DMA (buffer_load ... lds) into 3-deep XOR-swizzled rings.
+//   * S^T = K * Q^T is computed ("swapped" QK^T) so that one lane owns one query column of the
+//     32x32 accumulator: row max / row sum are in-lane + ONE half-wave exchange
+//     (v_permlane32_swap), no LDS, no shuffle trees.
+//   * P^T never leaves registers: the S^T accumulator layout is re-used directly as the MFMA B
+//     operand of O^T = V^T * P^T, and V^T fragments are fetched with the hardware transposing
+//     LDS read (ds_read_b64_tr_b16) using the SAME k-slot permutation.
+//   * softmax in base 2: p = exp2(s*c - m*c), c = log2(e)/sqrt(d)  (v_exp_f32 is exp2).
+//   * causal (bottom-right aligned, mask.h:172) skips fully masked tiles per workgroup AND per
+//     wave; only diagonal / tail tiles take the element mask.
+//   * O is normalised, rounded to fp16/bf16, staged through LDS and stored as whole rows.
+//   * two wave groups (waves 0-3 / 4-7) run the matrix phase of one against the softmax phase of the other.
+//
+// Semantics follow SURVEY.md Appendix A; dead rows produce O = 0 and LSE = 0.0
+// (flash_fwd_kernel.h:720-728,767-771) without relying on a zero pre-fill of the outputs.
+// Earlier alternatives (one-barrier-per-tile baseline, 4-wave variant, single-stream software pipeline) and the
+// timing-only ablation switches were removed from the product in round 2; they are in the history at commit a1ce086.
 #include "fa_device.hpp"
 #include "fa_params.hpp"
 
@@ -14,9 +34,6 @@
 // bit3: causal diagonal-band tiles run through the unmasked steady-state loop (what if a band tile cost a full tile?);
 // bit4: no wave-level causal skip inside the band (every wave computes every band tile);
 // bit5: no epilogue output (O staging + stores, LSE) - where does the per-workgroup fixed cost sit?; bit6: no Q load from HBM.
-#ifndef FA_ABL
-#define FA_ABL 0
-#endif
 
 namespace fa {
 
@@ -57,7 +74,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             v_boff = (int64_t)batch * p.v.batch, o_boff = (int64_t)batch * p.o.batch;
     if (p.cu_seqlens_q != nullptr) {
         const int q_beg = p.cu_seqlens_q[batch], k_beg = p.cu_seqlens_k[batch];
-        sq = p.cu_seqlens_q[batch + 1] - q_beg;
+        // a sequence longer than the declared max_seqlen_q is clamped: the padded LSE row holds max_seqlen_q entries only
+        sq = min(p.cu_seqlens_q[batch + 1] - q_beg, p.seqlen_q);
         sk = p.cu_seqlens_k[batch + 1] - k_beg;
         q_row0 = q_beg; k_row0 = k_beg;
         q_boff = k_boff = v_boff = o_boff = 0;
@@ -121,11 +139,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 
     u32x4 qf[KS];
 #pragma unroll
-#if FA_ABL & 64
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = u32x4{(uint32_t)tid * 0x3c003c00u, 0x3c003c00u + ks, (uint32_t)lane, 0x38003800u};
-#else
     for (int ks = 0; ks < KS; ++ks) qf[ks] = buf_load16(q_rs, (uint32_t)q_row * q_rowb + (2 * ks + hi) * 16);
-#endif
 
     f32x16 oacc[DB];
 #pragma unroll
@@ -141,14 +155,14 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         dma_tile(v_rs, dma_goff_v, 0u, vring);
         dma_tile(k_rs, dma_goff_k, (uint32_t)kFwdBlockN * k_rowb, kring + TILEB);
     }
+    // every wave reads rows DMA-ed by the other waves: own pieces landed (vmcnt), THEN the barrier (the back-off
+    // barrier of gfx950 does not imply a vmcnt drain; ROCm 7.2 happens to emit one here, this makes it a guarantee)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (group == 1) __syncthreads();          // group B runs one phase behind group A
 
     f32x16 sacc[2];
     u32x4 pf[4];
-#if FA_ABL & 4
-    u32x4 abl_kf = {0, 0, 0, 0}, abl_vf = {0, 0, 0, 0};
-#endif
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // u % 3, (u-1) % 3 == (u+2) % 3, (u+1) % 3
 
     // ---- phase bodies ---------------------------------------------------------------------------
@@ -158,19 +172,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int ts = 0; ts < 4; ++ts) {
-#if FA_ABL & 4
-                u32x4 vf;
-                if ((ts & 1) == 0) {
-                    const u32x2 a0 = lds_read_tr8(vbuf, v_rd[0][db] + ts * 16 * ROWB);
-                    const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
-                    abl_vf = u32x4{a0.x, a0.y, a1.x, a1.y};
-                }
-                vf = abl_vf;
-#else
                 const u32x2 a0 = lds_read_tr8(vbuf, v_rd[0][db] + ts * 16 * ROWB);
                 const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
                 const u32x4 vf = {a0.x, a0.y, a1.x, a1.y};
-#endif
                 oacc[db] = LP<T>::mfma(vf, pf[ts], oacc[db]);
             }
     };
@@ -182,12 +186,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-#if FA_ABL & 4
-                if ((ks & 1) == 0) abl_kf = lds_read16(kbuf, k_rd[ks] + bi * 32 * ROWB);
-                const u32x4 kf = abl_kf;
-#else
                 const u32x4 kf = lds_read16(kbuf, k_rd[ks] + bi * 32 * ROWB);
-#endif
                 sacc[bi] = LP<T>::mfma(kf, qf[ks], sacc[bi]);
             }
         }
@@ -256,16 +255,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#if FA_ABL & 2
-                const float pv = sacc[bi][r];
-#elif FA_ABL & 1
-                float pv = __builtin_fmaf(sacc[bi][r], c, -mc);   // exp -> one plain VALU op (asm: keeps hipcc from packing the fmas)
-                asm volatile("v_add_f32 %0, 0, %0" : "+v"(pv));
-                psum += pv;
-#else
                 const float pv = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc));
                 psum += pv;
-#endif
                 sacc[bi][r] = pv;
             }
         l_run += psum;
@@ -284,9 +275,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // sequence: no mask, no per-wave skipping -> a branch-free steady-state loop.  The remaining
     // (diagonal / ragged) tiles and the pipeline fill / drain go through the generic body.
     int n_main = min(n_tiles, sk / kFwdBlockN);
-#if !(FA_ABL & 8)
     if (CAUSAL) n_main = min(n_main, max(0, (m0 + delta + 1) / kFwdBlockN));
-#endif
 
     bool prev_active = false;                         // does this wave hold a P tile whose PV is pending?
     // every S phase ends with: this wave's LDS-DMA pieces have landed (vmcnt) -> workgroup barrier
@@ -296,11 +285,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     };
     auto generic_iter = [&](int u) {
         const bool in_range = u < n_tiles;
-#if FA_ABL & 16
-        const bool active = in_range;
-#else
         const bool active = in_range && (!CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta));
-#endif
         if (prev_active) pv_step();
         if (active) qk_step();
         if (!in_range) return;                        // drain iteration: only the pending PV
@@ -337,21 +322,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     for (; u <= n_tiles; ++u) generic_iter(u);        // diagonal / ragged tiles, then the drain
     if (group == 0) __syncthreads();          // group A waits for B's last phase (equal barrier counts)
 
-    // ---- epilogue (identical to fa_fwd_kernel) --------------------------------------------------
+    // ---- epilogue -----------------------------------------------------------------------------------
     const float l_tot = sum_both_halves(l_run);
     const float inv = l_tot > 0.f ? fast_rcp(l_tot) : 0.f;
     const float lse = l_tot > 0.f ? (m_run * c + fast_log2(l_tot)) * kLn2 : 0.f;
-#if FA_ABL & 32
-    {   // keep the whole computation alive with a data-dependent, never-taken store
-        float chk = lse;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) chk += oacc[db][r] * inv;
-        if (chk == 12345.678f) lse_base[q_row] = chk;
-        return;
-    }
-#endif
     if (hi == 0 && q_row < rows_here) lse_base[q_row] = lse;
     __syncthreads();
 #pragma unroll
@@ -382,7 +356,7 @@ static hipError_t launch_pp_t(const FwdKernelParams& kp, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_pp(FwdKernelParams kp, int dtype, hipStream_t stream) {
+hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, stream) : launch_pp_t<_Float16, 64>(kp, stream);

@@ -55,10 +55,7 @@ struct BwdKernelParams {
     float scale;
 };
 
-hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);      // dispatches on the selected schedule
-hipError_t launch_fwd_pp(FwdKernelParams kp, int dtype, hipStream_t stream);   // two-group ping-pong (default)
-hipError_t launch_fwd_sp(FwdKernelParams kp, int dtype, hipStream_t stream);   // software-pipelined single stream
-void set_fwd_impl(int impl);   // -1 = env/default, 0 = simple, 1 = pp, 2 = sp  (A/B timing and tests only)
+hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t stream);

@@ -53,10 +53,21 @@ fa_strides strides3(const at::Tensor& t) {
 }
 // The kernels take real strides, but rows/heads must stay 16-byte aligned; anything else is
 // densified (the reference assumes contiguous input without checking, flash_api.cpp:38-54).
+// NOTE: the densifying copy is a hidden extra HBM pass the reference never makes (it never checks); it only
+// triggers for layouts the kernels cannot address (unaligned base / strides, broadcast rows) and is counted in
+// g_densify_copies (exported as `densify_copies()`) so that a caller can see it happened.
+int64_t g_densify_copies = 0;
 at::Tensor dense_last(const at::Tensor& t) {
     bool ok = t.stride(-1) == 1 && (reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0);
     for (int i = 0; i < t.dim() - 1 && ok; ++i) ok = (t.stride(i) % 8 == 0);
-    return ok ? t : t.contiguous();
+    // the row (sequence) dimension is dim -3: an expand()-ed / overlapping row stride (< head_dim) is not addressable
+    if (ok && t.dim() >= 3 && t.size(-3) > 1) ok = t.stride(-3) >= t.size(-1);
+    if (ok) return t;
+    ++g_densify_copies;
+    return t.contiguous();
+}
+void check_same_device(const at::Tensor& q, const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.device() == q.device(), name, " must be on the same GPU device as q");
 }
 
 void check_cu_seqlens(const at::Tensor& cu_q, const at::Tensor& cu_k) {
@@ -105,6 +116,7 @@ std::vector<at::Tensor> mha_bwd(at::Tensor q, at::Tensor k, at::Tensor v, at::Te
     TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "q, k, v must be rank-4 tensors");
     TORCH_CHECK(out.dim() == 4 && dout.dim() == 4, "out and dout must be rank-4 tensors");
     check_qkv_common(q, k, v);
+    check_same_device(q, out, "out"); check_same_device(q, dout, "dout"); check_same_device(q, l, "l");
     const int64_t batch_size = q.size(0), seqlen_q = q.size(1), num_heads = q.size(2), head_size = q.size(3);
     const int64_t seqlen_k = k.size(1), num_heads_k = k.size(2);
     TORCH_CHECK(k.size(0) == batch_size && v.size(0) == batch_size, "k/v batch size must match q");
@@ -145,6 +157,7 @@ std::vector<at::Tensor> mha_varlen_fwd(at::Tensor q, at::Tensor k, at::Tensor v,
     TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3, "q, k, v must be rank-3 packed tensors");
     check_cu_seqlens(cu_seqlens_q, cu_seqlens_k);
     check_qkv_common(q, k, v);
+    check_same_device(q, cu_seqlens_q, "cu_seqlens_q"); check_same_device(q, cu_seqlens_k, "cu_seqlens_k");
     const int64_t batch_size = cu_seqlens_q.numel() - 1;
     TORCH_CHECK(k.size(0) == v.size(0), "k and v total tokens must match");
     TORCH_CHECK(k.size(1) == v.size(1), "k and v num_heads must match");
@@ -182,6 +195,8 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3, "q, k, v must be rank-3 packed tensors");
     check_cu_seqlens(cu_seqlens_q, cu_seqlens_k);
     check_qkv_common(q, k, v);
+    check_same_device(q, cu_seqlens_q, "cu_seqlens_q"); check_same_device(q, cu_seqlens_k, "cu_seqlens_k");
+    check_same_device(q, out, "out"); check_same_device(q, dout, "dout"); check_same_device(q, l, "l");
     const int64_t batch_size = cu_seqlens_q.numel() - 1;
     TORCH_CHECK(k.size(0) == v.size(0), "k and v total tokens must match");
     TORCH_CHECK(k.size(1) == v.size(1), "k and v num_heads must match");
@@ -230,4 +245,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("varlen_bwd", &mha_varlen_bwd, "Varlen backward pass");
     m.def("abi_version", []() { return fa_abi_version(); });
     m.def("build_info", []() { return std::string(fa_build_info()); });
+    m.def("densify_copies", []() { return g_densify_copies; }, "number of hidden .contiguous() copies made so far (0 for addressable layouts)");
 }

@@ -81,14 +81,6 @@ def lib():
     return _lib
 
 
-def set_fwd_impl(impl):
-    """debug / A-B timing hook (not in the public header): 'simple', 'pp', 'sp', 'simple4' or None (env/default)"""
-    L = lib()
-    L.fa_debug_set_fwd_impl.argtypes = [ctypes.c_int]
-    L.fa_debug_set_fwd_impl.restype = None
-    L.fa_debug_set_fwd_impl({None: -1, "simple": 0, "pp": 1, "sp": 2, "simple4": 3}[impl])
-
-
 def last_error() -> str:
     return lib().fa_last_error().decode()
 

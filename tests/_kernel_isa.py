@@ -71,7 +71,7 @@ def analyse(hip_source, extra_flags=()):
 
 
 if __name__ == "__main__":
-    for f in sys.argv[1:] or ["fa_fwd_pp.hip", "fa_fwd.hip", "fa_fwd_sp.hip", "fa_bwd.hip"]:
+    for f in sys.argv[1:] or ["fa_fwd_pp.hip", "fa_bwd.hip"]:
         for name, k in analyse(f).items():
             if "loops" not in k:
                 continue

@@ -29,18 +29,8 @@ def run_hip(g_or_tensors, gpu, causal, dtype, varlen=None):
     return tuple(t.float().cpu().numpy() for t in (o, lse, dq, dk, dv))
 
 
-@pytest.fixture(params=["pp", "simple", "sp", "simple4"])
-def fwd_impl(request):
-    """every forward schedule (ping-pong = shipped default; simple = bisecting aid; sp; simple4 = 4-wave / 128-row workgroups) must be correct"""
-    from flash_attn_turing import capi
-
-    capi.set_fwd_impl(request.param)
-    yield request.param
-    capi.set_fwd_impl(None)
-
-
 @pytest.mark.parametrize("name", U.golden_names())
-def test_golden_vectors(gpu, name, fwd_impl):
+def test_golden_vectors(gpu, name):
     g = U.load_golden(name)
     varlen = (g["cu_seqlens_q"], g["cu_seqlens_k"], g["sq"], g["sk"]) if g["varlen"] else None
     o, lse, dq, dk, dv = run_hip(g, gpu, g["causal"], g["dtype"], varlen)
@@ -65,7 +55,7 @@ ORACLE_CASES = [
 
 
 @pytest.mark.parametrize("b,sq,sk,h,hk,d,causal,dtype", ORACLE_CASES)
-def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype, fwd_impl):
+def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype):
     """Same seeded inputs through the HIP kernels and the CPU oracle with the reference's rounding points."""
     from oracle import attn_oracle as A
 

@@ -8,7 +8,7 @@ import pytest
 
 from _kernel_isa import analyse
 
-FILES = ["fa_fwd_pp.hip", "fa_fwd.hip", "fa_fwd_sp.hip", "fa_bwd.hip"]
+FILES = ["fa_fwd_pp.hip", "fa_bwd.hip"]
 # whole-kernel scratch that is known, outside every loop (prologue / epilogue), and bounded here so growth is noticed
 SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 64, "fa_bwd_dq_kernel": 64}
 # scratch ops INSIDE an MFMA loop: zero everywhere except the two D=64 backward kernels, which were deliberately squeezed to
@@ -28,7 +28,7 @@ def kernels():
 
 def test_every_kernel_was_analysed(kernels):
     with_loops = [k for k, v in kernels.items() if v.get("loops")]
-    assert len(kernels) >= 36 and len(with_loops) >= 32, (len(kernels), len(with_loops))
+    assert len(kernels) >= 20 and len(with_loops) >= 16, (len(kernels), len(with_loops))
     for (f, name), info in kernels.items():
         assert {"vgprs", "agprs", "scratch_bytes", "occupancy"} <= set(info), (f, name, info)
         # no vacuous passes: every MFMA kernel must have been seen WITH its MFMAs and at least one MFMA loop
@@ -54,7 +54,7 @@ def test_whole_kernel_scratch_is_zero_or_on_the_allow_list(kernels):
 
 def test_two_waves_per_simd_for_the_eight_wave_kernels(kernels):
     for (f, name), info in kernels.items():
-        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_fwd_sp_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel")):
+        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel")):
             assert info["occupancy"] >= 2, (f, name, info["occupancy"])
 
 

@@ -10,7 +10,6 @@ import torch  # noqa: E402
 from flash_attn_turing import capi  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--impl", default=None)
 ap.add_argument("--seq", type=int, default=8192)
 ap.add_argument("--b", type=int, default=4)
 ap.add_argument("--h", type=int, default=32)
@@ -26,8 +25,6 @@ gen = torch.Generator(device=dev).manual_seed(1)
 q, k, v, do = (torch.randn(a.b, a.seq, a.h, a.d, device=dev, dtype=dt, generator=gen) for _ in range(4))
 o = torch.empty_like(q)
 lse = torch.empty(a.b, a.h, a.seq, device=dev, dtype=torch.float32)
-if a.impl:
-    capi.set_fwd_impl(a.impl)
 dq, dk, dv, dsum = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(lse)
 for _ in range(a.iters):
     capi.mha_fwd(q, k, v, o, lse, bool(a.causal))
