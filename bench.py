@@ -15,12 +15,24 @@ communication is the timing barrier and a MAX all-reduce of the elapsed time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): `value` = whole-job
 TFLOP/s using the ALGORITHMIC FLOPs of SURVEY.md §8(d) (4*b*h*sq*sk*d, x1/2 causal),
-`roofline` for the dominant kernel (fa_fwd_kernel) from HIP-event timing on the launch stream,
+`roofline` for the dominant kernel (the forward kernel) from HIP-event timing on the launch stream,
 `cpu_baseline` = the CPU oracle (oracle/, the checker, never the product) timed on a bounded
 sample on rank 0 at N=1, plus PyTorch SDPA's CPU math path at BASELINE configs[0] as the
-north_star asks.  `extra` carries the other BASELINE configs measured after the timed region.
+north_star asks.  `extra` carries, after the timed region:
+  N = 1: the other BASELINE configs (with `roofline_bwd` for the three backward kernels of configs[3]) and the reference
+         README's seqlen sweep 512..16k (b4 h32 d128 fp16) next to PyTorch-ROCm SDPA on the same GPU;
+  N > 1: the same seqlen sweep STRONG-scaled over the N ranks (the b=4 x h=32 problem split by `plan_shards`: batch slices at
+         N = 2 / 4, batch x kv-head halves at N = 8, strided views, no copy, no collective) with per-point aggregate TFLOP/s and
+         efficiency against rank 0 running the whole problem alone in the same run, and BASELINE configs[4] itself
+         (non-causal 16k, b=4 per rank = b=32 at N=8) as a weak-scaled line.
+
+Communication: the timing harness needs a barrier and a scalar MAX, nothing else.  The default process group is gloo (cannot
+fail for want of a GPU fabric); with `--backend nccl` (default) an nccl (= RCCL) group is created on top and used for the
+barrier / reductions if — and only if — every rank could create it and complete a device all-reduce; otherwise the harness
+stays on gloo and says so in the JSON (`comm_backend`).
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -32,6 +44,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_DENSE_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_HBM_GBPS = 8000.0
+MFMA_FLOP_PER_CLK_PER_CU = 4096   # 4 SIMDs x (32x32x16 MFMA = 32768 FLOP / 32 clk)
+SWEEP_SEQS = (512, 1024, 2048, 4096, 8192, 16384)   # reference benchmark.sh:17-21 (power-of-two half), README.md:7-16
 
 WORKLOADS = {
     # name: (b, seq, h, h_k, d, dtype, causal, backward)
@@ -53,14 +67,21 @@ def fwd_bytes(b, sq, sk, h, hk, d):
 
 
 class Dist:
-    """Minimal one-process-per-GPU harness: env-driven init, barrier, MAX / SUM reductions."""
+    """Minimal one-process-per-GPU harness: env-driven init, barrier, MAX / SUM / MIN reductions.
 
-    def __init__(self, backend):
+    Default group: gloo (CPU tensors).  `want` == "nccl": an nccl (= RCCL) group is added with new_group() and adopted for
+    barrier / reductions only if all ranks created it and finished one device all-reduce (agreement by a gloo MIN);
+    any failure leaves the harness on gloo with the reason recorded in `comm_backend`."""
+
+    def __init__(self, want):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.backend = backend
-        # FA_BENCH_FORCE_PG=1: create the process group even at world size 1, so that the real nccl (= RCCL) init / barrier / all_reduce
+        self.want = want
+        self.group = None          # None = default (gloo) group
+        self.on_device = False
+        self.comm_backend = "none (single process)"
+        # FA_BENCH_FORCE_PG=1: create the process groups even at world size 1, so that the real init / barrier / all_reduce
         # calls of the N > 1 path can be exercised on a 1-GPU box (RCCL refuses two ranks on one device)
         self.enabled = self.world > 1 or os.environ.get("FA_BENCH_FORCE_PG") == "1"
         if self.enabled:
@@ -69,34 +90,61 @@ class Dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world,
+                                    timeout=datetime.timedelta(seconds=600))
             self.dist = dist
+            self.comm_backend = "gloo"
+
+    def try_nccl(self, device):
+        """called once the rank's device is set; returns the adopted backend string"""
+        if not self.enabled or self.want != "nccl":
+            return self.comm_backend
+        import torch
+
+        ok, why = 1.0, ""
+        grp = None
+        try:
+            grp = self.dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+            t = torch.ones(1, dtype=torch.float64, device=device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=grp)
+            torch.cuda.synchronize(device)
+            if int(t.item()) != self.world:
+                ok, why = 0.0, f"nccl all_reduce returned {t.item()} for world {self.world}"
+        except Exception as e:  # noqa: BLE001 - reported in the JSON, the harness continues on gloo
+            ok, why = 0.0, f"{type(e).__name__}: {str(e)[:160]}"
+        agree = torch.tensor([ok], dtype=torch.float64)
+        self.dist.all_reduce(agree, op=self.dist.ReduceOp.MIN)      # default (gloo) group: every rank learns the verdict
+        if agree.item() >= 1.0:
+            self.group, self.on_device, self.comm_backend = grp, True, "nccl (RCCL)"
+        else:
+            self.comm_backend = "gloo (nccl unavailable" + (f": {why}" if why else " on another rank") + ")"
+        return self.comm_backend
 
     def _tensor(self, x, device):
         import torch
 
-        return torch.tensor([x], dtype=torch.float64, device=device if self.backend == "nccl" else "cpu")
+        return torch.tensor([x], dtype=torch.float64, device=device if self.on_device else "cpu")
 
     def barrier(self, device=None):
-        if self.enabled:
-            if self.backend == "nccl":
-                self.dist.barrier(device_ids=[device.index if device is not None else self.local_rank])
-            else:
-                self.dist.barrier()
+        if not self.enabled:
+            return
+        if self.on_device:
+            self.dist.barrier(group=self.group, device_ids=[device.index if device is not None else self.local_rank])
+        else:
+            self.dist.barrier()
+
+    def _reduce(self, x, op, device):
+        if not self.enabled:
+            return x
+        t = self._tensor(x, device)
+        self.dist.all_reduce(t, op=op, group=self.group)
+        return float(t.item())
 
     def reduce_max(self, x, device=None):
-        if not self.enabled:
-            return x
-        t = self._tensor(x, device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return self._reduce(x, self.dist.ReduceOp.MAX, device) if self.enabled else x
 
     def reduce_sum(self, x, device=None):
-        if not self.enabled:
-            return x
-        t = self._tensor(x, device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return self._reduce(x, self.dist.ReduceOp.SUM, device) if self.enabled else x
 
     def close(self):
         if self.enabled:
@@ -119,6 +167,52 @@ def timed_region(step_fn, steps, warmup, dist, sync_fn, device=None):
     sync_fn()
     local = time.perf_counter() - t0
     return dist.reduce_max(local, device), local
+
+
+def strong_scaling_sweep(dist, make_point, sync_fn, device, seqs=SWEEP_SEQS, causals=(False, True), b=4, h=32, hk=32, d=128):
+    """The README seqlen sweep of ONE b x h problem split over the ranks by plan_shards (batch slices, then kv-head groups).
+
+    make_point(seq, causal, plan) -> (step_shard, step_whole): callables running this rank's shard / the whole problem once.
+    Per point: rank 0 alone times the whole problem (the in-run N = 1 reference), then all ranks time their shards between
+    barriers; aggregate TFLOP/s = whole-problem FLOPs / MAX-over-ranks time; efficiency = aggregate / (N x single-GPU rate)."""
+    from flash_attn_turing.sharding import plan_shards
+
+    plan = plan_shards(b, h, hk, dist.world)[dist.rank]
+    out = {}
+    for causal in causals:
+        for seq in seqs:
+            step_shard, step_whole = make_point(seq, causal, plan)
+            iters = 20 if seq <= 4096 else 6
+            flops = fwd_flops(b, seq, seq, h, d, causal)
+            single = None
+            if dist.rank == 0:
+                t1, _ = timed_region(step_whole, iters, 2, _NoDist, sync_fn, device)
+                single = flops * iters / t1 / 1e12
+            dist.barrier(device)
+            wall, local = timed_region(step_shard, iters, 2, dist, sync_fn, device)
+            agg = flops * iters / wall / 1e12
+            units = dist.reduce_sum(float(plan.n_units), device)
+            if dist.rank == 0:
+                out[f"{seq}{'_causal' if causal else ''}"] = {
+                    "seq": seq, "causal": causal, "ms": wall / iters * 1e3, "aggregate_tflops": agg,
+                    "frac_of_fp16_mfma_peak": agg / (PEAK_DENSE_FP16_TFLOPS * dist.world),
+                    "single_gpu_tflops_same_run": single, "efficiency_vs_1gpu": agg / (single * dist.world),
+                    "units_total": units,
+                    "shard": f"batch [{plan.batch_start},{plan.batch_stop}) x kv heads [{plan.head_k_start},{plan.head_k_stop}) on rank 0"}
+    return out
+
+
+class _NoDistT:
+    """stand-in for Dist when only one rank times something alone"""
+
+    def barrier(self, device=None):
+        pass
+
+    def reduce_max(self, x, device=None):
+        return x
+
+
+_NoDist = _NoDistT()
 
 
 def make_inputs(torch, device, b, s, h, hk, d, dtype, seed, backward):
@@ -152,22 +246,22 @@ def event_time_ms(torch, fn, iters, reps=1):
     return statistics.median(means)
 
 
-def hbm_traffic_from_profile(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  PMC collection cannot run inside the timed process, so this is the per-round profile value
-    (profiles/rNN_hbm_traffic.json), or None when no profile of this workload is committed."""
+def hbm_traffic_from_profile(workload, kernel):
+    """(bytes per launch, source) of the dominant kernel from the newest committed rocprofv3 PMC pass for this workload AND this
+    kernel (profiles/rNN_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC collection cannot run inside the timed process, so this is a committed
+    per-round value, tagged as such; (None, reason) when no profile of this workload / kernel is committed."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("workload") == workload:
-                return float(d["traffic_bytes_per_launch"])
+            if d.get("workload") == workload and d.get("kernel", "fa_fwd_pp_kernel") == kernel:
+                return float(d["traffic_bytes_per_launch"]), f"committed profile {os.path.basename(path)} (not measured in this run)"
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, f"no committed PMC profile for workload {workload} / kernel {kernel}"
 
 
 def parse_clockbench(out):
@@ -238,17 +332,57 @@ def cpu_baseline(args):
 
 
 def run_fake(args, dist):
-    """--fake-step: no GPU, no kernels — exercises sharding + timing aggregation under gloo (CPU tests)."""
+    """--fake-step: no GPU, no kernels — exercises sharding, timing aggregation, the strong-scaling sweep bookkeeping and the
+    nccl -> gloo fallback under gloo (CPU tests)."""
     from flash_attn_turing.sharding import plan_shards
 
+    backend = dist.comm_backend
+    if dist.enabled and dist.want == "nccl":
+        try:
+            import torch
+
+            backend = dist.try_nccl(torch.device("cuda", 0))      # no GPU on the CPU box: must come back as gloo + reason
+        except Exception as e:  # noqa: BLE001
+            backend = f"gloo (nccl probe raised {type(e).__name__})"
     plan = plan_shards(4 * dist.world, 32, 32, dist.world)[dist.rank]
     step = lambda: time.sleep(0.002 * (1 + dist.rank))
     wall, local = timed_region(step, args.steps, args.warmup, dist, lambda: None)
     units = dist.reduce_sum(float(plan.n_units))
+
+    def make_point(seq, causal, p):
+        # a fake kernel whose time is proportional to the (batch, head) units of the shard it is given
+        per_unit = 2e-5 * (seq / 512.0)
+        return (lambda: time.sleep(per_unit * p.n_units)), (lambda: time.sleep(per_unit * 4 * 32))
+
+    sweep = strong_scaling_sweep(dist, make_point, lambda: None, None, seqs=(512, 1024), causals=(False,))
     if dist.rank == 0:
         print(json.dumps({"metric": "fake_units_per_s", "value": units * args.steps / wall, "unit": "units/s",
                           "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": wall / args.steps * 1e3, "units_total": units, "local_ms": local * 1e3}))
+                          "ms_per_step": wall / args.steps * 1e3, "units_total": units, "local_ms": local * 1e3,
+                          "comm_backend": backend, "extra": {"sweep_strong": sweep}}))
+
+
+def bwd_rooflines(torch, capi, et, causal, b, s, h, d):
+    """Per-kernel roofline entries of the backward (C4): dot_do_o is HBM-bound, dQ and dK/dV are MFMA-bound; each timed alone with
+    HIP events through its stage-level C-ABI entry point.  `executed` FLOPs include the S / dP recomputation (6 and 8 x sq*sk*d
+    per head); the algorithmic backward FLOPs (2.5 x forward) are what `bwd_tflops` uses."""
+    p = capi.bwd_params(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"], et["dv"], et["dsum"], causal)
+    pair = b * h * float(s) * s * (0.5 if causal else 1.0)
+    out = {}
+    for name, kern, flop_mult in (("dot_do_o", "fa_bwd_dot_do_o_kernel", 0), ("dq", "fa_bwd_dq_kernel", 6), ("dkdv", "fa_bwd_dkdv_kernel", 8)):
+        f = lambda: capi.bwd_stage(name, p)
+        f(); torch.cuda.synchronize()
+        ms = event_time_ms(torch, f, 5, reps=5)
+        if flop_mult == 0:
+            byts = 2.0 * b * s * h * d * 2 + b * h * s * 4.0           # read O and dO once, write D
+            gbps = byts / ms / 1e6
+            out[name] = {"kernel": kern, "bound": "hbm", "avg_launch_ms": ms, "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": byts}
+        else:
+            tf = flop_mult * pair * d / ms / 1e9
+            out[name] = {"kernel": kern, "bound": "mfma", "avg_launch_ms": ms, "achieved": tf, "peak": PEAK_DENSE_FP16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / PEAK_DENSE_FP16_TFLOPS, "executed_flops_per_launch": flop_mult * pair * d}
+    return out
 
 
 def main():
@@ -264,7 +398,7 @@ def main():
     ap.add_argument("--cpu-sample-seq", type=int, default=4096)
     args = ap.parse_args()
 
-    dist = Dist("gloo" if args.fake_step else args.backend)
+    dist = Dist(args.backend)
     if dist.world != args.gpus and dist.world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dist.world}")
     if args.gpus > 1 and dist.world == 1:
@@ -279,11 +413,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path is HIP-only, there is no CPU fallback")
     from flash_attn_turing import capi   # fails loudly if the HIP build is missing
+    from flash_attn_turing.sharding import shard_tensor
 
     # one rank per GPU; the modulo only matters when the harness itself is exercised with more ranks
     # than devices (e.g. --backend gloo with 2 ranks on a 1-GPU box)
     device = torch.device("cuda", dist.local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    comm_backend = dist.try_nccl(device)
     b, s, h, hk, d, dtype, causal, backward = WORKLOADS[args.workload]
     t = make_inputs(torch, device, b, s, h, hk, d, dtype, 1234 + dist.rank, backward)
 
@@ -299,16 +435,55 @@ def main():
     value = flops_rank * dist.world / (wall / args.steps) / 1e12
 
     # dominant-kernel roofline: forward kernel alone, HIP events on the launch stream
+    fwd_kernel = capi.fwd_kernel_name(d)
     fwd_only = lambda: capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
     k_ms = event_time_ms(torch, fwd_only, max(5, args.steps))
     k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "fa_fwd_pp_kernel", "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
+    traffic, traffic_source = hbm_traffic_from_profile(args.workload, fwd_kernel) if dist.rank == 0 else (None, None)
+    prop = torch.cuda.get_device_properties(device)
+    sclk_ghz = getattr(prop, "clock_rate", 0) / 1e6
+    roofline = {"bound": "mfma", "kernel": fwd_kernel, "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
                 "unit": "TFLOP/s", "frac": k_tflops / PEAK_DENSE_FP16_TFLOPS,
-                "traffic": hbm_traffic_from_profile(args.workload) if dist.rank == 0 else None,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": k_ms, "algorithmic_flops_per_launch": fwd_flops(b, s, s, h, d, causal),
-                "algorithmic_hbm_gbps": fwd_bytes(b, s, s, h, hk, d) / (k_ms * 1e-3) / 1e9}
+                "algorithmic_hbm_gbps": fwd_bytes(b, s, s, h, hk, d) / (k_ms * 1e-3) / 1e9,
+                "peak_derivation": {"cus": prop.multi_processor_count, "sclk_ghz": sclk_ghz, "flop_per_clk_per_cu": MFMA_FLOP_PER_CLK_PER_CU,
+                                    "cus_x_sclk_x_4096_tflops": prop.multi_processor_count * sclk_ghz * MFMA_FLOP_PER_CLK_PER_CU / 1e3}}
 
     extra = {}
+    if not args.no_extra and dist.world > 1:
+        del t
+        torch.cuda.empty_cache()
+        state = {}
+
+        def make_point(seq, cz, plan):
+            # whole tensors on every rank (same seed), the rank's shard = strided views of them (no copy)
+            if state.get("seq") != seq:
+                state.clear()
+                torch.cuda.empty_cache()
+                w = make_inputs(torch, device, 4, seq, 32, 32, 128, "fp16", 99, False)
+                qs, os_ = shard_tensor(w["q"], plan, False), shard_tensor(w["o"], plan, False)
+                ks, vs = shard_tensor(w["k"], plan, True), shard_tensor(w["v"], plan, True)
+                lse_s = torch.empty(qs.shape[0], qs.shape[2], seq, device=device, dtype=torch.float32)
+                state.update(seq=seq, w=w, shard=(qs, ks, vs, os_, lse_s))
+            w, (qs, ks, vs, os_, lse_s) = state["w"], state["shard"]
+            ps = capi.fwd_params(qs, ks, vs, os_, lse_s, cz) if qs.numel() else None
+            pw = capi.fwd_params(w["q"], w["k"], w["v"], w["o"], w["lse"], cz)
+            return (lambda: capi.run_fwd(ps) if ps is not None else None), (lambda: capi.run_fwd(pw))
+
+        extra["sweep_strong_b4_h32_d128_fp16"] = strong_scaling_sweep(dist, make_point, sync, device)
+        state.clear()
+        torch.cuda.empty_cache()
+        # BASELINE configs[4]: forward, b=32 (= 4 per rank at N=8), seq 16384, non-causal, weak-scaled over the ranks
+        eb, es, eh, ehk, ed, edt, ec, _ = WORKLOADS["c5shard"]
+        et = make_inputs(torch, device, eb, es, eh, ehk, ed, edt, 777 + dist.rank, False)
+        f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], ec)
+        w5, _ = timed_region(f, 6, 2, dist, sync, device)
+        if dist.rank == 0:
+            agg = fwd_flops(eb, es, es, eh, ed, ec) * dist.world * 6 / w5 / 1e12
+            extra["c5_weak_noncausal_16k"] = {"config": f"BASELINE configs[4] shape: fwd b={eb * dist.world} (4 per rank) seq=16384 h=32 d=128 fp16 non-causal",
+                                              "ms": w5 / 6 * 1e3, "aggregate_tflops": agg, "frac_of_fp16_mfma_peak": agg / (PEAK_DENSE_FP16_TFLOPS * dist.world)}
+        del et
     if not args.no_extra and dist.rank == 0 and dist.world == 1:
         del t
         torch.cuda.empty_cache()
@@ -327,29 +502,31 @@ def main():
                 g(); sync()
                 bms = event_time_ms(torch, g, 3, reps=5)
                 extra[name].update({"bwd_ms": bms, "bwd_tflops": 2.5 * ff / bms / 1e9,
-                                    "fwd_bwd_tflops": 3.5 * ff / (ms + bms) / 1e9})
+                                    "fwd_bwd_tflops": 3.5 * ff / (ms + bms) / 1e9,
+                                    "roofline_bwd": bwd_rooflines(torch, capi, et, ec, eb, es, eh, ed)})
             del et
             torch.cuda.empty_cache()
-        # seqlen sweep of the reference's published chart (README.md:7-16): b4 h32 d128, no mask
-        sweep = {}
-        for ss in (512, 1024, 2048, 4096, 8192, 16384):
-            et = make_inputs(torch, device, 4, ss, 32, 32, 128, "fp16", 99, False)
-            f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], False)
-            f(); sync()
-            ms = event_time_ms(torch, f, 20 if ss <= 4096 else 8)
-            sweep[str(ss)] = {"ms": ms, "tflops": fwd_flops(4, ss, ss, 32, 128, False) / ms / 1e9}
-            # the reference's headline comparison (README.md:16 "around 2x faster than PyTorch attention"), on THIS GPU:
-            # PyTorch-ROCm's own fused SDPA on the same tensors ((b,h,s,d) strided views, no copy)
-            try:
-                qt, kt, vt = (et[n].permute(0, 2, 1, 3) for n in ("q", "k", "v"))
-                g = lambda: torch.nn.functional.scaled_dot_product_attention(qt, kt, vt)
-                g(); sync()
-                sms = event_time_ms(torch, g, 20 if ss <= 4096 else 8)
-                sweep[str(ss)].update({"torch_sdpa_ms": sms, "speedup_vs_torch_sdpa": sms / ms})
-            except Exception as exc:  # noqa: BLE001
-                sweep[str(ss)]["torch_sdpa_error"] = str(exc)[:80]
-            del et
-        extra["sweep_b4_h32_d128_fp16_noncausal"] = sweep
+        # seqlen sweep of the reference's published chart (README.md:7-16): b4 h32 d128
+        for cz in (False, True):
+            sweep = {}
+            for ss in SWEEP_SEQS:
+                et = make_inputs(torch, device, 4, ss, 32, 32, 128, "fp16", 99, False)
+                f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], cz)
+                f(); sync()
+                ms = event_time_ms(torch, f, 20 if ss <= 4096 else 8, reps=3)
+                sweep[str(ss)] = {"ms": ms, "tflops": fwd_flops(4, ss, ss, 32, 128, cz) / ms / 1e9}
+                # the reference's headline comparison (README.md:16 "around 2x faster than PyTorch attention"), on THIS GPU:
+                # PyTorch-ROCm's own fused SDPA on the same tensors ((b,h,s,d) strided views, no copy)
+                try:
+                    qt, kt, vt = (et[n].permute(0, 2, 1, 3) for n in ("q", "k", "v"))
+                    g = lambda: torch.nn.functional.scaled_dot_product_attention(qt, kt, vt, is_causal=cz)
+                    g(); sync()
+                    sms = event_time_ms(torch, g, 20 if ss <= 4096 else 8)
+                    sweep[str(ss)].update({"torch_sdpa_ms": sms, "speedup_vs_torch_sdpa": sms / ms})
+                except Exception as exc:  # noqa: BLE001
+                    sweep[str(ss)]["torch_sdpa_error"] = str(exc)[:80]
+                del et
+            extra["sweep_b4_h32_d128_fp16_" + ("causal" if cz else "noncausal")] = sweep
 
     cpu = None
     if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline:
@@ -361,7 +538,6 @@ def main():
         if "tflops" in ceiling:
             roofline["frac_of_sustained_measured"] = k_tflops / ceiling["tflops"]
     if dist.rank == 0:
-        prop = torch.cuda.get_device_properties(device)
         out = {
             "metric": "attention_fwd_tflops" if not backward else "attention_fwd_bwd_tflops",
             "value": value, "unit": "TFLOP/s", "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
@@ -373,6 +549,7 @@ def main():
                        "global_batch": b * dist.world, "seq_len": s, "parallelism": f"batch-sharded x{dist.world}, no collective",
                        "flops_def": "4*b*h*sq*sk*d (x0.5 causal) [SURVEY.md 8d]"},
             "frac_of_fp16_mfma_peak": value / (PEAK_DENSE_FP16_TFLOPS * dist.world),
+            "comm_backend": comm_backend,
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
             "device": {"name": prop.name or getattr(prop, "gcnArchName", ""), "arch": getattr(prop, "gcnArchName", ""), "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,
                        "peak_used_tflops": PEAK_DENSE_FP16_TFLOPS},

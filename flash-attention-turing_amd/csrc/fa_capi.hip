@@ -91,6 +91,8 @@ double fa_fwd_bytes(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, in
     return 2.0 * ((double)b * sq * h * d * 2.0 + (double)b * sk * hk * d * 2.0) + (double)b * h * sq * 4.0;
 }
 
+const char* fa_fwd_kernel_name(int32_t d) { return fa::fwd_kernel_name(d); }
+
 int fa_run_mha_fwd(const fa_fwd_params* p, void* stream) {
     if (p == nullptr) return fail(FA_ERR_NULL_POINTER, "params is NULL");
     int rc = check_common(p->b, p->seqlen_q, p->seqlen_k, p->h, p->h_k, p->d, p->dtype);
@@ -166,6 +168,22 @@ int fa_bwd_dot_do_o(const fa_bwd_params* p, void* stream) {
     if (rc) return rc;
     if (p->b == 0 || p->seqlen_q == 0) return FA_OK;
     return hip_status(fa::launch_bwd_dot_do_o(kp, p->dtype, (hipStream_t)stream), "fa_bwd_dot_do_o launch");
+}
+
+int fa_bwd_dq(const fa_bwd_params* p, void* stream) {
+    fa::BwdKernelParams kp;
+    int rc = fill_bwd(p, kp);
+    if (rc) return rc;
+    if (p->b == 0 || p->seqlen_q == 0) return FA_OK;
+    return hip_status(fa::launch_bwd_dq(kp, p->dtype, (hipStream_t)stream), "fa_bwd_dq launch");
+}
+
+int fa_bwd_dkdv(const fa_bwd_params* p, void* stream) {
+    fa::BwdKernelParams kp;
+    int rc = fill_bwd(p, kp);
+    if (rc) return rc;
+    if (p->b == 0 || p->seqlen_k == 0) return FA_OK;
+    return hip_status(fa::launch_bwd_dkdv(kp, p->dtype, (hipStream_t)stream), "fa_bwd_dkdv launch");
 }
 
 int fa_run_mha_bwd(const fa_bwd_params* p, void* stream) {

@@ -356,6 +356,8 @@ static hipError_t launch_pp_t(const FwdKernelParams& kp, hipStream_t stream) {
     return hipGetLastError();
 }
 
+const char* fwd_kernel_name(int) { return "fa_fwd_pp_kernel"; }
+
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;

@@ -56,6 +56,7 @@ struct BwdKernelParams {
 };
 
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);
+const char* fwd_kernel_name(int d);
 hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t stream);

@@ -66,19 +66,27 @@ def lib():
         L.fa_run_mha_fwd.argtypes = [ctypes.POINTER(FwdParams), _vp]
         L.fa_run_mha_bwd.argtypes = [ctypes.POINTER(BwdParams), _vp]
         L.fa_bwd_dot_do_o.argtypes = [ctypes.POINTER(BwdParams), _vp]
+        L.fa_bwd_dq.argtypes = [ctypes.POINTER(BwdParams), _vp]
+        L.fa_bwd_dkdv.argtypes = [ctypes.POINTER(BwdParams), _vp]
         L.fa_mha_fwd.argtypes = [_vp] * 5 + [_i32] * 8 + [_vp]
         L.fa_mha_bwd.argtypes = [_vp] * 10 + [_i32] * 8 + [_vp]
         L.fa_mha_varlen_fwd.argtypes = [_vp] * 7 + [_i32] * 8 + [_vp]
         L.fa_mha_varlen_bwd.argtypes = [_vp] * 12 + [_i32] * 8 + [_vp]
-        for n in ("fa_run_mha_fwd", "fa_run_mha_bwd", "fa_bwd_dot_do_o", "fa_mha_fwd", "fa_mha_bwd",
+        for n in ("fa_run_mha_fwd", "fa_run_mha_bwd", "fa_bwd_dot_do_o", "fa_bwd_dq", "fa_bwd_dkdv", "fa_mha_fwd", "fa_mha_bwd",
                   "fa_mha_varlen_fwd", "fa_mha_varlen_bwd"):
             getattr(L, n).restype = ctypes.c_int
         L.fa_fwd_flops.argtypes = [_i32] * 6
         L.fa_fwd_flops.restype = ctypes.c_double
         L.fa_fwd_bytes.argtypes = [_i32] * 6
         L.fa_fwd_bytes.restype = ctypes.c_double
+        L.fa_fwd_kernel_name.argtypes = [_i32]
+        L.fa_fwd_kernel_name.restype = ctypes.c_char_p
         _lib = L
     return _lib
+
+
+def fwd_kernel_name(d) -> str:
+    return lib().fa_fwd_kernel_name(int(d)).decode()
 
 
 def last_error() -> str:
@@ -116,3 +124,46 @@ def mha_bwd(q, k, v, o, lse, dout, dq, dk, dv, dsum, causal, stream=None):
     check(lib().fa_mha_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), dout.data_ptr(),
                            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(),
                            b, sq, sk, h, hk, d, dtype_code(q.dtype), int(causal), s))
+
+
+def bwd_params(q, k, v, o, lse, dout, dq, dk, dv, dsum, causal):
+    """fa_bwd_params for contiguous (b, s, h, d) torch tensors (stage-level entry points: fa_bwd_dot_do_o / fa_bwd_dq / fa_bwd_dkdv)"""
+    b, sq, h, d = q.shape
+    sk, hk = k.shape[1], k.shape[2]
+    p = BwdParams()
+    p.q, p.k, p.v, p.o, p.dout, p.lse = (t.data_ptr() for t in (q, k, v, o, dout, lse))
+    p.dq, p.dk, p.dv, p.dsoftmax_sum = (t.data_ptr() for t in (dq, dk, dv, dsum))
+    p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d = b, sq, sk, h, hk, d
+    p.dtype, p.is_causal = dtype_code(q.dtype), int(causal)
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o), ("do_stride", dout),
+                    ("dq_stride", dq), ("dk_stride", dk), ("dv_stride", dv)):
+        setattr(p, name, Strides(t.stride(0), t.stride(1), t.stride(2)))
+    return p
+
+
+def bwd_stage(name, params, stream=None):
+    """run one backward launch: name in {'dot_do_o', 'dq', 'dkdv'}"""
+    import torch
+
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    check(getattr(lib(), "fa_bwd_" + name)(ctypes.byref(params), s))
+
+
+def fwd_params(q, k, v, o, lse, causal):
+    """fa_fwd_params for (b, s, h, d) torch tensors with arbitrary batch / row / head strides (e.g. shard views)"""
+    b, sq, h, d = q.shape
+    sk, hk = k.shape[1], k.shape[2]
+    p = FwdParams()
+    p.q, p.k, p.v, p.o, p.lse = (t.data_ptr() for t in (q, k, v, o, lse))
+    p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d = b, sq, sk, h, hk, d
+    p.dtype, p.is_causal = dtype_code(q.dtype), int(causal)
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
+        setattr(p, name, Strides(t.stride(0), t.stride(1), t.stride(2)))
+    return p
+
+
+def run_fwd(params, stream=None):
+    import torch
+
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    check(lib().fa_run_mha_fwd(ctypes.byref(params), s))

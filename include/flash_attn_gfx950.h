@@ -158,6 +158,11 @@ int fa_mha_varlen_bwd(const void* q, const void* k, const void* v, const void* o
 /* D = rowsum(dO * O) alone (replaces flash_bwd_dot_do_o_kernel, flash_bwd_preprocess_kernel.h:23-96);
  * exposed because it is the one HBM-bound kernel on the path and is measured separately. */
 int fa_bwd_dot_do_o(const fa_bwd_params* params, void* stream);
+/* The other two launches of run_flash_bwd, individually (flash_bwd_launch_template.h:95-146): dQ and dK/dV.  Both read
+ * params->dsoftmax_sum, i.e. fa_bwd_dot_do_o must have run on the same stream before.  fa_run_mha_bwd == the three in order;
+ * exposed so that each kernel can be timed / profiled against its own roofline (bench.py `roofline_bwd`). */
+int fa_bwd_dq(const fa_bwd_params* params, void* stream);
+int fa_bwd_dkdv(const fa_bwd_params* params, void* stream);
 
 /* ---- measurement helpers ----------------------------------------------------------------- */
 /* Algorithmic FLOPs of one forward call (4*b*h*sq*sk*d, causal counts only visible pairs);
@@ -165,6 +170,9 @@ int fa_bwd_dot_do_o(const fa_bwd_params* params, void* stream);
 double fa_fwd_flops(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal);
 /* Algorithmic HBM bytes of one forward call: q,k,v,o once + lse. */
 double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d);
+/* Name of the forward kernel the library dispatches to for this head_dim (what a profiler's kernel trace will show; lets a
+ * benchmark tie a committed PMC profile to the kernel that actually ran). */
+const char* fa_fwd_kernel_name(int32_t d);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,21 @@ def round_like_output(ref, dtype):
     return r.view(np.float32)
 
 
-def assert_close(x, ref, dtype, name, scale=1.0):
+MARGINS = {}     # test family -> tensor -> worst RAW metrics seen (reference-style, no slack); flushed by conftest at session end
+PLAIN_SK_MIN = 64
+
+
+def _record_margin(name, raw, dtype, plain):
+    fam = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split("::")[-1].split("[")[0].split(" ")[0]
+    tensor = name.split(" ")[0]
+    slot = MARGINS.setdefault(fam, {}).setdefault(f"{tensor}/{dtype}", dict(max_abs=0.0, mean_abs=0.0, mean_rel=0.0, cases=0, plain_bound_cases=0))
+    for k in ("max_abs", "mean_abs", "mean_rel"):
+        slot[k] = max(slot[k], raw[k])
+    slot["cases"] += 1
+    slot["plain_bound_cases"] += int(plain)
+
+
+def assert_close(x, ref, dtype, name, scale=1.0, sk=None):
     """THE stated tolerance of this repo (DESIGN.md "Parity"): the reference's three bounds
     (max_abs 5e-3, mean_abs 2e-4, mean_rel 1e-2 for fp16; x8 for bf16), made magnitude-aware so they stay
     meaningful on the reference grid's degenerate shapes (e.g. sk = 1: dV sums 1024 N(0,1) terms,
@@ -63,6 +77,11 @@ def assert_close(x, ref, dtype, name, scale=1.0):
         the expectation is identically ~0 (a single visible key makes dS = P (dP - D) vanish analytically
         while any kernel leaves ~1e-7 of summation-order noise).
     For |values| <~ 1 (every non-degenerate case) these reduce to the reference's plain bounds.
+    `sk` (keys per query, when the caller knows it): every case with sk >= 64 must ALSO meet the reference's PLAIN bounds on
+    max_abs and mean_abs (reference test_flash_attn.py:407-414: no ulp slack, no floor) against the expectation in the output
+    format - the magnitude-aware form above exists for the degenerate sk < 64 shapes of the reference grid only.  The plain
+    mean_rel (|d| / max(|ref|, 1e-6), dominated by the few elements whose expectation is ~0) is recorded, not asserted.
+    The worst raw metrics per test family go to MARGINS (-> gpurun_out/parity_margins.json).
     Returns the raw reference-style metrics for logging."""
     xa = np.asarray(x, dtype=np.float64)
     assert np.isfinite(xa).all(), f"{name}: non-finite values"
@@ -71,6 +90,11 @@ def assert_close(x, ref, dtype, name, scale=1.0):
     if xa.size == 0:
         return raw
     tol, ulp = TOL[dtype], ULP[dtype]
+    plain = sk is not None and sk >= PLAIN_SK_MIN
+    _record_margin(name, raw, dtype, plain)
+    if plain:
+        assert raw["max_abs"] <= tol["max_abs"] * scale, f"{name} PLAIN max_abs={raw['max_abs']:.3e} > {tol['max_abs'] * scale:.3e} (sk={sk})"
+        assert raw["mean_abs"] <= tol["mean_abs"] * scale, f"{name} PLAIN mean_abs={raw['mean_abs']:.3e} > {tol['mean_abs'] * scale:.3e} (sk={sk})"
     diff, aref = np.abs(xa - ref), np.abs(ref)
     m_max = float(np.maximum(diff - ulp * aref, 0.0).max())
     m_mean = float(diff.mean() - 0.5 * ulp * aref.mean())

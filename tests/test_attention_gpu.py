@@ -35,11 +35,12 @@ def test_golden_vectors(gpu, name):
     varlen = (g["cu_seqlens_q"], g["cu_seqlens_k"], g["sq"], g["sk"]) if g["varlen"] else None
     o, lse, dq, dk, dv = run_hip(g, gpu, g["causal"], g["dtype"], varlen)
     o, dq, dk, dv, lse = U.subsample(g, o, dq, dk, dv, lse)
-    U.assert_close(o, g["o"], g["dtype"], "O")
+    sk = None if g["varlen"] else g["sk"]      # plain reference bounds asserted on top whenever sk >= 64 (tests/_util.py)
+    U.assert_close(o, g["o"], g["dtype"], "O", sk=sk)
     assert np.abs(lse - g["lse"]).max(initial=0) <= U.LSE_TOL, "LSE"
-    U.assert_close(dq, g["dq"], g["dtype"], "dQ")
-    U.assert_close(dk, g["dk"], g["dtype"], "dK")
-    U.assert_close(dv, g["dv"], g["dtype"], "dV")
+    U.assert_close(dq, g["dq"], g["dtype"], "dQ", sk=sk)
+    U.assert_close(dk, g["dk"], g["dtype"], "dK", sk=sk)
+    U.assert_close(dv, g["dv"], g["dtype"], "dV", sk=sk)
 
 
 ORACLE_CASES = [
@@ -67,11 +68,11 @@ def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype):
     o, lse, dq, dk, dv = run_hip(t, gpu, causal, dtype)
     # backward oracle fed with OUR forward outputs would hide forward errors; feed the oracle's own
     dq_ref, dk_ref, dv_ref = A.attn_bwd(t["q"], t["k"], t["v"], o_ref, lse_ref, t["dout"], causal=causal, round_mode=mode)
-    U.assert_close(o, o_ref, dtype, "O")
+    U.assert_close(o, o_ref, dtype, "O", sk=sk)
     assert np.abs(lse - lse_ref).max() <= U.LSE_TOL
-    U.assert_close(dq, dq_ref, dtype, "dQ")
-    U.assert_close(dk, dk_ref, dtype, "dK")
-    U.assert_close(dv, dv_ref, dtype, "dV")
+    U.assert_close(dq, dq_ref, dtype, "dQ", sk=sk)
+    U.assert_close(dk, dk_ref, dtype, "dK", sk=sk)
+    U.assert_close(dv, dv_ref, dtype, "dV", sk=sk)
 
 
 # the reference's (seqlen_q, seqlen_k) grid, de-duplicated (reference test_flash_attn.py:262-343)
@@ -119,7 +120,7 @@ def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, caus
         o, lse = F.fwd(q, k, v, causal)
         dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
         for got, ref, name in ((o, o_ref, "O"), (dq, dq_ref, "dQ"), (dk, dk_ref, "dK"), (dv, dv_ref, "dV")):
-            m = U.assert_close(got.float().cpu().numpy(), ref.cpu().numpy(), "fp16", f"{name} sq={sq} sk={sk}")
+            m = U.assert_close(got.float().cpu().numpy(), ref.cpu().numpy(), "fp16", f"{name} sq={sq} sk={sk}", sk=sk)
             worst[name] = max(worst.get(name, 0.0), m["max_abs"])
         assert (lse.cpu() - lse_ref.cpu()).abs().max().item() <= U.LSE_TOL, f"LSE sq={sq} sk={sk}"
     print("worst max_abs", worst)
@@ -152,10 +153,10 @@ def test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, d, causal):
             qs, ks = slice(cu_q[i], cu_q[i + 1]), slice(cu_k[i], cu_k[i + 1])
             o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q[qs][None], k[ks][None], v[ks][None], do[qs][None], causal)
             tag = f"seq{i} lq={lq[i]} lk={lk[i]}"
-            U.assert_close(o[qs].float().cpu().numpy(), o_r[0].cpu().numpy(), "fp16", "O " + tag)
-            U.assert_close(dq[qs].float().cpu().numpy(), dq_r[0].cpu().numpy(), "fp16", "dQ " + tag)
-            U.assert_close(dk[ks].float().cpu().numpy(), dk_r[0].cpu().numpy(), "fp16", "dK " + tag)
-            U.assert_close(dv[ks].float().cpu().numpy(), dv_r[0].cpu().numpy(), "fp16", "dV " + tag)
+            U.assert_close(o[qs].float().cpu().numpy(), o_r[0].cpu().numpy(), "fp16", "O " + tag, sk=int(lk[i]))
+            U.assert_close(dq[qs].float().cpu().numpy(), dq_r[0].cpu().numpy(), "fp16", "dQ " + tag, sk=int(lk[i]))
+            U.assert_close(dk[ks].float().cpu().numpy(), dk_r[0].cpu().numpy(), "fp16", "dK " + tag, sk=int(lk[i]))
+            U.assert_close(dv[ks].float().cpu().numpy(), dv_r[0].cpu().numpy(), "fp16", "dV " + tag, sk=int(lk[i]))
             assert (lse[i, :, : lq[i]] - lse_r[0]).abs().max().item() <= U.LSE_TOL, "LSE " + tag
             assert (lse[i, :, lq[i]:] == 0).all(), "padded LSE must stay zero"
 
@@ -170,7 +171,7 @@ def test_bf16_backward_medium(gpu):
         o, lse = F.fwd(q, k, v, causal)
         dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
         for got, ref, name in ((o, o_r, "O"), (dq, dq_r, "dQ"), (dk, dk_r, "dK"), (dv, dv_r, "dV")):
-            U.assert_close(got.float().cpu().numpy(), ref.cpu().numpy(), "bf16", name)
+            U.assert_close(got.float().cpu().numpy(), ref.cpu().numpy(), "bf16", name, sk=640)
         assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
 
 

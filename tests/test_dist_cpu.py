@@ -47,6 +47,35 @@ def test_two_rank_gloo_timing_and_unit_aggregation():
     assert abs(r["value"] - r["units_total"] * 5 / (r["ms_per_step"] * 5e-3)) / r["value"] < 1e-6
 
 
+def test_two_rank_strong_scaling_sweep_aggregation():
+    """the N > 1 seqlen sweep: one b=4 x h=32 problem split by plan_shards, per-point aggregate over the MAX time, efficiency against
+    rank 0 running the whole problem alone in the same run (fake kernel: time proportional to the (batch, head) units it is given)"""
+    r = json.loads([l for l in _launch(2)[0][0].splitlines() if l.startswith("{")][0])
+    sweep = r["extra"]["sweep_strong"]
+    assert set(sweep) == {"512", "1024"}
+    for key, pt in sweep.items():
+        assert pt["units_total"] == 4 * 32, pt                      # the two shards cover the whole problem exactly once
+        assert pt["shard"].startswith("batch [0,2) x kv heads [0,32)"), pt["shard"]
+        assert pt["single_gpu_tflops_same_run"] > 0 and pt["aggregate_tflops"] > 0
+        # a kernel whose time is proportional to its units scales ~linearly: efficiency near 1 (sleep granularity leaves slack)
+        assert 0.6 <= pt["efficiency_vs_1gpu"] <= 1.3, pt
+        assert abs(pt["efficiency_vs_1gpu"] - pt["aggregate_tflops"] / (2 * pt["single_gpu_tflops_same_run"])) < 1e-9
+
+
+def test_nccl_unavailable_falls_back_to_gloo():
+    """--backend nccl on a box where RCCL cannot come up (no GPU here): every rank must agree to stay on gloo, the run must finish
+    and say so in the JSON instead of dying (an nccl init failure must not lose the SCALE record)"""
+    outs = _launch(2, extra=("--backend", "nccl"))
+    r = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+    assert r["comm_backend"].startswith("gloo (nccl"), r["comm_backend"]
+    assert r["n_gpus"] == 2 and r["units_total"] == 2 * 4 * 32 and r["ms_per_step"] >= 4.0
+
+
+def test_gloo_backend_is_reported():
+    r = json.loads([l for l in _launch(2, extra=("--backend", "gloo"))[0][0].splitlines() if l.startswith("{")][0])
+    assert r["comm_backend"] == "gloo"
+
+
 def test_single_process_fake_step():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fake-step", "--steps", "3", "--warmup", "1"],

@@ -28,9 +28,9 @@ def _heads(rng):
     return h, hk
 
 
-def _check(got, ref, dt, tag):
+def _check(got, ref, dt, tag, sk=None):
     for g, r, name in zip(got, ref, ("O", "dQ", "dK", "dV")):
-        U.assert_close(g.float().cpu().numpy(), r.cpu().numpy(), dt, f"{name} {tag}")
+        U.assert_close(g.float().cpu().numpy(), r.cpu().numpy(), dt, f"{name} {tag}", sk=sk)
 
 
 @pytest.mark.parametrize("case", range(48))
@@ -71,7 +71,7 @@ def test_dense_random_shapes(gpu, case):
         o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, causal)
     o, lse = F.fwd(q, k, v, causal)
     dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
-    _check((o, dq, dk, dv), (o_r, dq_r, dk_r, dv_r), dt, tag)
+    _check((o, dq, dk, dv), (o_r, dq_r, dk_r, dv_r), dt, tag, sk=sk)
     assert (lse - lse_r).abs().max().item() <= U.LSE_TOL, "LSE " + tag
     for t, name in ((o, "O"), (dq, "dQ"), (dk, "dK"), (dv, "dV"), (lse, "LSE")):
         assert torch.isfinite(t.float()).all(), f"non-finite {name} {tag}"
@@ -129,7 +129,7 @@ def test_varlen_random_batches_with_empty_sequences(gpu, case):
             tag += " vs C oracle"
         else:
             o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q[qs][None], k[ks][None], v[ks][None], do[qs][None], causal)
-        _check((o[qs], dq[qs], dk[ks], dv[ks]), (o_r[0], dq_r[0], dk_r[0], dv_r[0]), dt, tag)
+        _check((o[qs], dq[qs], dk[ks], dv[ks]), (o_r[0], dq_r[0], dk_r[0], dv_r[0]), dt, tag, sk=int(lk[i]))
         assert (lse[i, :, : lq[i]] - lse_r[0]).abs().max().item() <= U.LSE_TOL, "LSE " + tag
         assert (lse[i, :, lq[i]:] == 0).all(), "padded LSE must stay zero " + tag
 
@@ -168,7 +168,7 @@ def test_dense_large_odd_shapes(gpu, case):
         o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, causal)
     o, lse = F.fwd(q, k, v, causal)
     dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
-    _check((o, dq, dk, dv), (o_r, dq_r, dk_r, dv_r), dt, tag)
+    _check((o, dq, dk, dv), (o_r, dq_r, dk_r, dv_r), dt, tag, sk=sk)
     assert (lse - lse_r).abs().max().item() <= U.LSE_TOL, "LSE " + tag
 
 
