@@ -441,7 +441,7 @@ def main():
     k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12
     traffic, traffic_source = hbm_traffic_from_profile(args.workload, fwd_kernel) if dist.rank == 0 else (None, None)
     prop = torch.cuda.get_device_properties(device)
-    sclk_ghz = getattr(prop, "clock_rate", 0) / 1e6
+    sclk_ghz = max(capi.device_clock_khz(device.index), 0) / 1e6     # hipDeviceAttributeClockRate (torch's props carry no clock)
     roofline = {"bound": "mfma", "kernel": fwd_kernel, "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
                 "unit": "TFLOP/s", "frac": k_tflops / PEAK_DENSE_FP16_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_source,

@@ -225,14 +225,12 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
                 f32x16 sacc, dpacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+                // S^T and dP^T chains interleaved: consecutive MFMAs never share an accumulator; per-chain order unchanged
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const u32x4 kf = lds_read16(kbuf, row_rd[ks] + bi * 32 * ROWB);
-                    sacc = LP<T>::mfma(kf, qf[ks], sacc);          // S^T = K Q^T
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
                     const u32x4 vf = lds_read16(vbuf, row_rd[ks] + bi * 32 * ROWB);
+                    sacc = LP<T>::mfma(kf, qf[ks], sacc);          // S^T = K Q^T
                     dpacc = LP<T>::mfma(vf, dof[ks], dpacc);       // dP^T = V dO^T
                 }
                 // P = exp(s*scale - LSE) (flash_bwd_kernel.h:474), dS = P * (dP - D) (:490)
@@ -399,8 +397,13 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         hq = head_k * p.h_ratio + g;
         m0 = (qt_begin + (it - g * tiles_per_head)) * kKvBlockM;
     };
-    float st_stat = 0.f;
-    auto issue_tile = [&](int it, int buf) {               // Q/dO tile `it` -> ring slot buf (DMA) ; stats -> register
+    // Q/dO tile `it` -> ring slot buf, and its 64 LSE / D values -> the stats slot, ALL by LDS-DMA: nothing returns to a VGPR, so
+    // hipcc has no reason to wait.  (Until round 2 the statistics went through a register on waves 0 / 1 under an exec-masked
+    // branch; hipcc answered with `s_waitcnt vmcnt(0)` at the top of every iteration - a write-after-write guard on that register
+    // for the paths that skipped the branch - i.e. right behind the DMA issue, exposing the full L2 / HBM latency of the NEXT
+    // tile in front of the MFMAs of the current one: 58 % of wave cycles parked, 35 % MFMA busy.)  LSE stays in natural-log units in
+    // LDS; the consumer scales it.
+    auto issue_tile = [&](int it, int buf) {
         int hq, m0;
         tile_coords(it, hq, m0);
         const int rows = min(kKvBlockM, sq - m0);
@@ -414,16 +417,12 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             dma16_to_lds_hidden(q_srd, q_src[i], lds0 + OFF_Q + buf * TILEB + piece * 1024);
             dma16_to_lds_hidden(do_srd, do_src[i], lds0 + OFF_DO + buf * TILEB + piece * 1024);
         }
-        // threads 0..63 fetch LSE (scaled to log2 units), 64..127 fetch D; rows past the end -> 0
-        const int64_t so = ((int64_t)batch * p.h + hq) * p.lse_row_stride + m0;
-        st_stat = 0.f;
-        if (tid < 2 * kKvBlockM) {
-            const int r = tid & (kKvBlockM - 1);
-            if (r < rows) st_stat = (tid < kKvBlockM) ? p.lse_ptr[so + r] * kLog2e : p.dsum_ptr[so + r];
+        if (wave < 2) {      // wave 0: LSE rows, wave 1: D rows (wave-uniform scalar branch); rows past the end arrive as 0
+            const int64_t so = ((int64_t)batch * p.h + hq) * p.lse_row_stride + m0;
+            const float* sb = uniform_ptr((wave == 0 ? p.lse_ptr : p.dsum_ptr) + so);
+            const srd_t st_srd = make_srd(sb, (uint32_t)rows * 4u);
+            dma4_to_lds_hidden(st_srd, (uint32_t)lane * 4u, lds0 + OFF_STAT + buf * STATB + wave * (kKvBlockM * 4));
         }
-    };
-    auto land_stats = [&](int buf) {
-        if (tid < 2 * kKvBlockM) *(FA_LDS float*)(stat + buf * STATB + tid * 4) = st_stat;
     };
 
     // ---- prologue: this workgroup's K and V tiles + the first Q/dO tile ---------------------------
@@ -433,10 +432,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         dma16_to_lds_hidden(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
         dma16_to_lds_hidden(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
     }
-    if (n_iters > 0) {
-        issue_tile(0, 0);
-        land_stats(0);
-    }
+    if (n_iters > 0) issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -469,16 +465,14 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            // S and dP chains interleaved (consecutive MFMAs on different accumulators, see fa_bwd_dq_kernel)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 qa = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
                 const u32x4 kf = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
-                sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 da = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
                 const u32x4 vf = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
+                sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
                 dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
             }
             f32x16 pacc;
@@ -491,32 +485,44 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -l4[e]));
+                    float pv = fast_exp2(__builtin_fmaf(sacc[r], c, l4[e] * -kLog2e));
                     if constexpr (CAUSAL) pv = (8 * g4 + e >= thr) ? pv : 0.f;
                     pacc[r] = pv;
                     sacc[r] = pv * (dpacc[r] - d4[e]);
                 }
             }
+            // dV^T += dO^T P and dK^T += Q^T dS: 4*DB MFMAs whose A operands are transposed LDS reads.  The accumulators are inline-asm
+            // operands, so hipcc has no latency model for these MFMAs and used to issue each read pair right in front of its
+            // consumer (s_waitcnt lgkmcnt(0) before every MFMA: the LDS latency was exposed 4*DB times per tile).  The reads are
+            // software-pipelined by hand instead - fragment j + PF is requested before MFMA j - and the order is pinned.
+            u32x4 pfr[2], dsfr[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const u32x4 pf = pack_c_half<T>(pacc, half);        // P rounded (flash_bwd_kernel.h:1359)
-                const u32x4 dsf = pack_c_half<T>(sacc, half);       // dS rounded (:1360)
-                const int ts = 2 * qh + half;                       // 16-row k-slice of the 64-row tile
+                pfr[half] = pack_c_half<T>(pacc, half);             // P rounded (flash_bwd_kernel.h:1359)
+                dsfr[half] = pack_c_half<T>(sacc, half);            // dS rounded (:1360)
+            }
+            constexpr int NST = 4 * DB, PF = 3;                     // step j = (half, db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
+            auto rd_frag = [&](int j) {
+                const int half = j / (2 * DB), db = (j >> 1) % DB, ts = 2 * qh + half;
+                FA_LDS char* src = (j & 1) ? qbuf : dobuf;
+                const u32x2 a0 = lds_read_tr8(src, tr_rd[0][db] + ts * 16 * ROWB);
+                const u32x2 a1 = lds_read_tr8(src, tr_rd[1][db] + ts * 16 * ROWB);
+                return u32x4{a0.x, a0.y, a1.x, a1.y};
+            };
+            u32x4 frag[NST];
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const u32x2 a0 = lds_read_tr8(dobuf, tr_rd[0][db] + ts * 16 * ROWB);
-                    const u32x2 a1 = lds_read_tr8(dobuf, tr_rd[1][db] + ts * 16 * ROWB);
-                    const u32x4 dot = {a0.x, a0.y, a1.x, a1.y};
-                    LP<T>::mfma_agpr(dvacc[db], dot, pf);           // dV^T += dO^T P    (AGPR accumulator)
-                    const u32x2 b0 = lds_read_tr8(qbuf, tr_rd[0][db] + ts * 16 * ROWB);
-                    const u32x2 b1 = lds_read_tr8(qbuf, tr_rd[1][db] + ts * 16 * ROWB);
-                    const u32x4 qt = {b0.x, b0.y, b1.x, b1.y};
-                    LP<T>::mfma_agpr(dkacc[db], qt, dsf);           // dK^T += Q^T dS    (AGPR accumulator)
-                }
+            for (int j = 0; j < PF; ++j) frag[j] = rd_frag(j);
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                if (j + PF < NST) frag[j + PF] = rd_frag(j + PF);
+                __builtin_amdgcn_sched_barrier(0);
+                const int half = j / (2 * DB), db = (j >> 1) % DB;
+                if (j & 1) LP<T>::mfma_agpr(dkacc[db], frag[j], dsfr[half]);      // dK^T += Q^T dS    (AGPR accumulator)
+                else LP<T>::mfma_agpr(dvacc[db], frag[j], pfr[half]);             // dV^T += dO^T P    (AGPR accumulator)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (more) land_stats(buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
         __syncthreads();
     }
 

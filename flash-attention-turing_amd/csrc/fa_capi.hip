@@ -93,6 +93,12 @@ double fa_fwd_bytes(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, in
 
 const char* fa_fwd_kernel_name(int32_t d) { return fa::fwd_kernel_name(d); }
 
+int fa_device_clock_khz(int32_t device) {
+    int khz = 0;
+    const hipError_t e = hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, device);
+    return e == hipSuccess ? khz : -(int)e;
+}
+
 int fa_run_mha_fwd(const fa_fwd_params* p, void* stream) {
     if (p == nullptr) return fail(FA_ERR_NULL_POINTER, "params is NULL");
     int rc = check_common(p->b, p->seqlen_q, p->seqlen_k, p->h, p->h_k, p->d, p->dtype);

@@ -159,14 +159,30 @@ FA_DEV srd_t make_srd(const void* base, uint32_t num_bytes) {
     return s;
 }
 FA_DEV uint32_t lds_addr(const FA_LDS char* p) { return (uint32_t)(uintptr_t)p; }
+// SAVE_M0 = false: for kernels that contain NO compiler-visible LDS-DMA (nothing else hipcc generates for them reads M0), where
+// the two extra SALU per piece are measurable (0.6 % of the forward); tests/test_kernel_resources_cpu.py checks that such a
+// kernel touches M0 only inside these statements.
+template <bool SAVE_M0 = true>
 FA_DEV void dma16_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds_byte_addr) {
     // s_nop 4: SGPRs of the descriptor / M0 source may have just been written by v_readfirstlane
     // or SALU; s_nop 0 after the M0 write (hazard tables 11 / 38).
     // M0 is compiler-reserved (the compiler-visible LDS-DMA builtin addresses LDS through it too) and an
     // "m0" clobber is not honoured for reserved registers, so the statement saves and restores it: a kernel
     // may mix this with dma16_to_lds() without relying on where hipcc happens to re-materialise M0.
+    if constexpr (SAVE_M0) {
+        uint32_t keep;
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
+    } else {
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
+    }
+}
+
+// 4 bytes per lane: rsrc[voffset] -> lds_byte_addr + 4 * lane (256 B per wave instruction).  Used for per-row fp32 statistics.
+FA_DEV void dma4_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds_byte_addr) {
     uint32_t keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
 }
 

@@ -79,10 +79,16 @@ def lib():
         L.fa_fwd_flops.restype = ctypes.c_double
         L.fa_fwd_bytes.argtypes = [_i32] * 6
         L.fa_fwd_bytes.restype = ctypes.c_double
+        L.fa_device_clock_khz.argtypes = [_i32]
+        L.fa_device_clock_khz.restype = ctypes.c_int
         L.fa_fwd_kernel_name.argtypes = [_i32]
         L.fa_fwd_kernel_name.restype = ctypes.c_char_p
         _lib = L
     return _lib
+
+
+def device_clock_khz(device_index=0) -> int:
+    return int(lib().fa_device_clock_khz(int(device_index)))
 
 
 def fwd_kernel_name(d) -> str:

@@ -173,6 +173,9 @@ double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, in
 /* Name of the forward kernel the library dispatches to for this head_dim (what a profiler's kernel trace will show; lets a
  * benchmark tie a committed PMC profile to the kernel that actually ran). */
 const char* fa_fwd_kernel_name(int32_t d);
+/* Peak shader clock of `device` in kHz (hipDeviceAttributeClockRate), or a negative HIP error code: with 256 CUs x 4096 FLOP/clk/CU
+ * it derives the dense fp16 MFMA peak a benchmark quotes (256 x 2.4 GHz x 4096 = 2.5 PFLOP/s). */
+int fa_device_clock_khz(int32_t device);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,10 @@ def analyse(hip_source, extra_flags=()):
         m = re.search(r"^\.Lfunc_end\d+:", body, re.M)
         body = body[:m.start()] if m else body[:body.rindex("s_endpgm")]
         info["mfma_total"] = len(re.findall(r"v_mfma", body))
+        # M0 outside hand-written asm statements (;;#ASMSTART .. ;;#ASMEND): kernels whose LDS-DMA does not save / restore M0 rely on
+        # hipcc itself never using it
+        outside = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", body, flags=re.S)
+        info["m0_outside_asm"] = len(re.findall(r"\bm0\b", outside))
         info["loops"] = []
         for lab, seg in _loops(body):
             n = len(re.findall(r"v_mfma", seg))

@@ -70,6 +70,17 @@ def test_d64_kernels_fit_two_workgroups_per_cu(kernels):
     assert seen == 12, seen
 
 
+def test_forward_kernels_touch_m0_only_in_their_own_lds_dma_statements(kernels):
+    """fa_fwd_pp issues every LDS-DMA from inline asm WITHOUT saving / restoring M0 (dma16_to_lds_hidden<false>); that is only sound while
+    nothing hipcc generates for those kernels reads or writes M0 (no compiler-visible LDS-DMA, no indirect register indexing)"""
+    seen = 0
+    for (f, name), info in kernels.items():
+        if "fa_fwd_pp_kernel" in name:
+            seen += 1
+            assert info["m0_outside_asm"] == 0, (name, info["m0_outside_asm"])
+    assert seen >= 8
+
+
 def test_guard_detects_the_known_pathology():
     """the detector must fire on the construct it exists for: the wave-level skip branch around asm-accumulator MFMAs"""
     ks = analyse("fa_bwd.hip", extra_flags=["-DFA_TEST_DKDV_SKIP_BRANCH"])

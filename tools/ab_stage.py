@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Interleaved in-process A/B of individual kernels between builds of the library: forward, dQ and dK/dV each timed alone
+through the stage-level C-ABI entry points (fa_run_mha_fwd / fa_bwd_dq / fa_bwd_dkdv).  Builds without the stage entry points
+(round 1) are timed on the whole backward only.  Usage: ab_stage.py A.so B.so [...] [--only substr] [--stages fwd,dq,dkdv,bwd]"""
+import argparse
+import ctypes
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flash-attention-turing_amd"))
+from flash_attn_turing import capi  # noqa: E402  (struct definitions only)
+
+F16, BF16 = torch.float16, torch.bfloat16
+CONFIGS = {
+    "c4 bf16 d128 8k": (4, 8192, 32, 32, 128, BF16, False),
+    "bf16 d128 8k causal": (4, 8192, 32, 32, 128, BF16, True),
+    "c3 fp16 d128 16k causal": (4, 16384, 32, 32, 128, F16, True),
+    "c2 fp16 d128 4k": (4, 4096, 32, 32, 128, F16, False),
+    "fp16 d128 2k": (4, 2048, 32, 32, 128, F16, False),
+    "fp16 d128 1k": (4, 1024, 32, 32, 128, F16, False),
+    "fp16 d128 512": (4, 512, 32, 32, 128, F16, False),
+    "fp16 d128 1k causal": (4, 1024, 32, 32, 128, F16, True),
+    "fp16 d64 8k": (4, 8192, 32, 32, 64, F16, False),
+    "fp16 d64 8k causal": (4, 8192, 32, 32, 64, F16, True),
+    "bf16 d128 8k mqa causal": (4, 8192, 32, 1, 128, BF16, True),
+    "fp16 d128 gqa 4k causal": (4, 4096, 32, 8, 128, F16, True),
+}
+
+
+def load(path):
+    L = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    L.fa_run_mha_fwd.argtypes = [ctypes.POINTER(capi.FwdParams), vp]
+    L.fa_run_mha_bwd.argtypes = [ctypes.POINTER(capi.BwdParams), vp]
+    for n in ("fa_bwd_dot_do_o", "fa_bwd_dq", "fa_bwd_dkdv"):
+        if hasattr(L, n):
+            getattr(L, n).argtypes = [ctypes.POINTER(capi.BwdParams), vp]
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--stages", default="fwd,dq,dkdv")
+    a = ap.parse_args()
+    libs = {f"{chr(65 + i)}:{os.path.basename(p)[6:-3]}": load(p) for i, p in enumerate(a.libs)}
+    stages = a.stages.split(",")
+    dev = torch.device("cuda:0")
+    for cname, (b, s, h, hk, d, dt, causal) in CONFIGS.items():
+        if a.only and not any(x in cname for x in a.only.split(",")):
+            continue
+        gen = torch.Generator(device=dev).manual_seed(1)
+        q, do = (torch.randn(b, s, h, d, device=dev, dtype=dt, generator=gen) for _ in range(2))
+        k, v = (torch.randn(b, s, hk, d, device=dev, dtype=dt, generator=gen) for _ in range(2))
+        o, dq = torch.empty_like(q), torch.empty_like(q)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        lse, dsum = (torch.empty(b, h, s, device=dev, dtype=torch.float32) for _ in range(2))
+        pf = capi.fwd_params(q, k, v, o, lse, causal)
+        pb = capi.bwd_params(q, k, v, o, lse, do, dq, dk, dv, dsum, causal)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        first = list(libs.values())[0]
+        assert first.fa_run_mha_fwd(ctypes.byref(pf), st) == 0
+        assert first.fa_run_mha_bwd(ctypes.byref(pb), st) == 0      # o, lse, dsum valid for every stage of every build
+        torch.cuda.synchronize()
+        ref = {}
+        for stage in stages:
+            fl = 4.0 * b * h * s * s * d * (0.5 if causal else 1.0) * {"fwd": 1, "dq": 1.5, "dkdv": 2, "bwd": 2.5}[stage]
+            times, outs = {n: [] for n in libs}, {}
+
+            def run(n):
+                L = libs[n]
+                if stage == "fwd":
+                    return L.fa_run_mha_fwd(ctypes.byref(pf), st)
+                if stage == "bwd" or not hasattr(L, "fa_bwd_dq"):
+                    return L.fa_run_mha_bwd(ctypes.byref(pb), st)
+                return getattr(L, "fa_bwd_" + stage)(ctypes.byref(pb), st)
+            for n in libs:
+                assert run(n) == 0
+                torch.cuda.synchronize()
+                outs[n] = [t.clone() for t in ((o, lse) if stage == "fwd" else (dq,) if stage == "dq" else (dk, dv) if stage == "dkdv" else (dq, dk, dv))]
+            for _ in range(a.rounds):
+                for n in libs:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(a.iters):
+                        run(n)
+                    e1.record()
+                    e1.synchronize()
+                    times[n].append(e0.elapsed_time(e1) / a.iters)
+            na = list(libs)[0]
+            ma = statistics.median(times[na])
+            for n, ts in times.items():
+                med = statistics.median(ts)
+                whole = stage in ("dq", "dkdv") and not hasattr(libs[n], "fa_bwd_dq")
+                same = (not whole) and all(torch.equal(x, y) for x, y in zip(outs[na], outs[n])) if not (stage in ("dq", "dkdv") and not hasattr(libs[na], "fa_bwd_dq")) else None
+                print(f"{cname:26s} {stage:5s} {n:28s} {med:8.3f} ms (min {min(ts):8.3f}) {fl / med / 1e9:6.0f} TF{' [whole bwd]' if whole else ''}  vs A {med / ma:6.4f}  same bits: {same}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
