@@ -33,6 +33,7 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 EXT_PATH = os.path.join(PKG, "_C.so")
 
 HIP_SOURCES = ["fa_fwd_pp.hip", "fa_bwd.hip", "fa_capi.hip"]
+EXTRA_FLAGS = {}      # per-file extra flags (none at present)
 HIP_HEADERS = ["fa_device.hpp", "fa_params.hpp", os.path.join(INCLUDE, "flash_attn_gfx950.h")]
 # -amdgpu-mfma-vgpr-form: builtin MFMAs keep their result in VGPRs even in kernels that may use the
 # accumulator half of the register file (the dK/dV kernel parks its 128 long-lived accumulator
@@ -78,7 +79,7 @@ def hipcc_path():
 def build_kernels(force=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
-    stamp = _digest(srcs + hdrs, " ".join(HIPCC_FLAGS))
+    stamp = _digest(srcs + hdrs, " ".join(HIPCC_FLAGS) + repr(sorted(EXTRA_FLAGS.items())))
     if not force and not _stale(LIB_PATH, stamp):
         print(f"[build] {LIB_NAME} up to date")
         return LIB_PATH
@@ -88,7 +89,7 @@ def build_kernels(force=False):
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-I", CSRC, "-I", INCLUDE, "-c", s, "-o", o]
+        cmd = [hipcc_path()] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-I", CSRC, "-I", INCLUDE, "-c", s, "-o", o]
         print("[build]", " ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))
     for p in procs:

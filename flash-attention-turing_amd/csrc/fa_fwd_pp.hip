@@ -29,10 +29,6 @@
 #include <type_traits>
 
 
-#ifndef FA_X_PRESCALE
-#define FA_X_PRESCALE 0
-#endif
-
 namespace fa {
 
 constexpr int kFwdThreads = 512;
@@ -236,44 +232,13 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
     float m_run = kNegBig, l_run = 0.f;
-    // PRESCALE (fp16): Q is multiplied by scale*log2(e) once per item (in fp32, rounded to nearest: no systematic scale error), so
-    // the QK^T MFMA already delivers scores in log2 units, and its accumulator chain is SEEDED with -m (a 16-register tile that is
-    // rewritten only when the running max is refreshed, i.e. almost never): the MFMA result is the exp2 argument itself.  That
-    // removes one VALU instruction per score element (the fma with the scale and the max) from the softmax phase - and the issue
-    // slots of a SIMD, shared by the two waves, are what bounds this kernel: ~6.7 non-MFMA instructions per MFMA cost ~41 cycles
-    // per MFMA instead of 32 (tools/phase_timing.py; MI355X_MICROARCH.md: <= 5 fillers per MFMA are free).  m_run is then kept in log2
-    // units.  seed_m: the max the seed tile encodes (== m_run once the row has seen a key; 0 before).  thr: refresh threshold on the
-    // seeded scores (kPpDeferLog2 once the row has seen a key; -huge before, so the first visible key always refreshes).
-    // bf16 keeps the fma form: rounding Q*c to 8 mantissa bits moves LSE by up to 1.5e-3 (measured in round 1), beyond the 1e-3 bound.
-    constexpr bool PRESCALE = FA_X_PRESCALE && std::is_same<T, _Float16>::value && D == 128;   // D = 64: no room for the seed tile in 128 VGPRs
-    f32x16 seedt;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) seedt[r] = 0.f;
-    float seed_m = 0.f, thr = -3.0e38f;
-    auto prescale_q = [&]() {
-        if constexpr (PRESCALE) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t x = qf[ks][w];
-                    qf[ks][w] = LP<T>::pack2(LP<T>::to_float((uint16_t)(x & 0xffffu)) * c, LP<T>::to_float((uint16_t)(x >> 16)) * c);
-                }
-        }
-    };
     auto reset_row_state = [&]() {
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
         m_run = kNegBig; l_run = 0.f;
-        if constexpr (PRESCALE) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) seedt[r] = 0.f;
-            seed_m = 0.f; thr = -3.0e38f;
-        }
     };
-    prescale_q();
 
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
     auto dma_k_tile = [&](const srd_t& srd, int t, int slot) {
@@ -318,11 +283,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         FA_LDS char* kbuf = kring + ring_u * TILEB;
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi) {
-            if constexpr (PRESCALE) sacc[bi] = seedt;          // the chain starts from -m (C operand of the first MFMA)
-            else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 kf = lds_read16(kbuf, k_rd[ks] + bi * 32 * ROWB);
@@ -336,20 +298,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // phase starts on an MFMA instead of on an LDS round trip.  Measured with per-phase s_memtime stamps (tools/phase_timing.py,
     // profiles/r2_fwd_phase_timing.log): the period of the ping-pong is the SUM of the two groups' matrix phases (the softmax
     // phases hide behind them), and a matrix phase took 1270 cycles for 1024 cycles of MFMA issue.
-#ifndef FA_X_PF
-#define FA_X_PF 4
-#endif
-#ifndef FA_X_PF64
-#define FA_X_PF64 2
-#endif
-#ifndef FA_X_SB
-#define FA_X_SB 1
-#endif
-    constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? FA_X_PF64 : FA_X_PF;
+    constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? 2 : 4;      // fragments in flight; D = 64 has 128 VGPRs only
     auto m_frag = [&](int j, int slot_v, int slot_k) -> u32x4 {
-#ifdef FA_X_FAKE_SLOT0
-        slot_v = 0; slot_k = 0;       // TIMING-ONLY ablation: constant ring slot (results wrong)
-#endif
         if (j < NPV) {
             const int db = j / 4, ts = j % 4;
             FA_LDS char* vbuf = vring + slot_v * TILEB;
@@ -372,25 +322,18 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
             if (j + PF < NST) fr[j + PF] = m_frag(j + PF, ring_um1, ring_u);
-#if FA_X_SB
             __builtin_amdgcn_sched_barrier(0);
-#endif
             if (j < NPV) {
                 oacc[j / 4] = LP<T>::mfma(fr[j], pf[j % 4], oacc[j / 4]);
             } else {
                 const int i = j - NPV, ks = i / 2, bi = i % 2;
                 if (ks == 0) {
-                    if constexpr (PRESCALE) sacc[bi] = seedt;
-                    else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
-                    }
+                    for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
                 }
                 sacc[bi] = LP<T>::mfma(fr[j], qf[ks], sacc[bi]);
             }
-#if FA_X_SB
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     };
     // K(u+2) starts flying at the very END of M(u), after the phase's last LDS read, where the wave would otherwise just wait
@@ -431,38 +374,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
         mx = max_both_halves(mx);
         float psum = 0.f;
-        if constexpr (PRESCALE) {
-            // sacc = s*c - seed_m.  Refresh (rare after a row's first visible key) when some row of the wave outgrew its reference
-            // by > 2^kPpDeferLog2: P stays < 64, exact in fp16 and in the fp32 accumulators.
-            if (__builtin_amdgcn_ballot_w64(mx > thr) != 0) {
-                const float m_new = fmaxf(m_run, mx + seed_m);           // stays kNegBig while the row sees nothing (mx = -inf)
-                const float alpha = fast_exp2(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-                const bool seen = m_new > kNegBig;
-                const float seed_new = seen ? m_new : 0.f, dshift = seed_new - seed_m;
-#pragma unroll
-                for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[bi][r] -= dshift;
-                seed_m = seed_new;
-                thr = seen ? kPpDeferLog2 : -3.0e38f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) seedt[r] = -seed_new;
-            }
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = fast_exp2(sacc[bi][r]);
-                    psum += pv;
-                    sacc[bi][r] = pv;
-                }
-        } else {
+        {
             // refresh the running max only if some row of the wave outgrew it by > 2^kPpDeferLog2
             if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > kPpDeferLog2) != 0) {
                 const float m_new = fmaxf(m_run, mx);
@@ -482,9 +394,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float pv = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc));
-#ifndef FA_X_NOSUM
                     psum += pv;
-#endif
                     sacc[bi][r] = pv;
                 }
         }
@@ -509,13 +419,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         const int ln = opaque_lane_value<PERSIST>(lane), q_row = wave * 32 + (ln & 31), hi = ln >> 5;     // shadows: not hoistable
         const float l_tot = sum_both_halves(l_run);
         const float inv = l_tot > 0.f ? fast_rcp(l_tot) : 0.f;
-        const float lse = l_tot > 0.f ? ((PRESCALE ? m_run : m_run * c) + fast_log2(l_tot)) * kLn2 : 0.f;
-#ifdef FA_X_TIMING
-        const bool lse_ok = (q_row & 31) < 8 || (q_row & 31) > 13;
-#else
-        const bool lse_ok = true;
-#endif
-        if (hi == 0 && q_row < rows_here && lse_ok) p.lse_ptr[((int64_t)it.batch * p.h + it.head) * p.lse_row_stride + it.tile * kFwdBlockM + q_row] = lse;
+        const float lse = l_tot > 0.f ? (m_run * c + fast_log2(l_tot)) * kLn2 : 0.f;
+        if (hi == 0 && q_row < rows_here) p.lse_ptr[((int64_t)it.batch * p.h + it.head) * p.lse_row_stride + it.tile * kFwdBlockM + q_row] = lse;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -553,7 +458,6 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             if (prev_active) pv_step();
             epilogue(done_it);
             reset_row_state();
-            prescale_q();
             pending = false;
             if (has_next) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the epilogue's staging reads have returned
@@ -577,52 +481,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         int u = 0;
         if (n_main > 0) {
             iteration(0, no{});
-#ifdef FA_X_TIMING
-            // TIMING BUILD ONLY (tools/build_variant.py -DFA_X_TIMING; results are wrong: the LSE rows carry cycle counts)
-            uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};
-            auto now = [&]() { uint64_t t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; };
-            for (u = 1; u < n_main; ++u) {
-                const uint64_t t0 = now();
-                pv_step();
-                const uint64_t t1 = now();
-                qk_step();
-                const uint64_t t2 = now();
-                issue_dma_k(u);
-                __syncthreads();
-                const uint64_t t3 = now();
-                issue_dma_v(u);
-                softmax_step(u, no{});
-                const uint64_t t4 = now();
-                end_s_phase();
-                const uint64_t t5 = now();
-                advance_ring();
-                tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4; tacc[5] += 1;
-            }
-            if (lane == 0) {
-                float* dbg = p.lse_ptr + ((int64_t)cur_it.batch * p.h + cur_it.head) * p.lse_row_stride + cur_it.tile * kFwdBlockM + wave * 32;
-                for (int i = 0; i < 6; ++i) dbg[8 + i] = (float)tacc[i];
-            }
-#else
-#ifndef FA_X_KDMA_IN_S
-#define FA_X_KDMA_IN_S 1
-#endif
             if (n_main > 1) m_prefetch(ring_um1, ring_u);
             for (u = 1; u < n_main; ++u) {        // steady state: branch-free
                 m_phase();
-#if !FA_X_KDMA_IN_S
-                issue_dma_k(u);
-#endif
                 __syncthreads();
-#if FA_X_KDMA_IN_S
                 issue_dma_k(u);
-#endif
                 issue_dma_v(u);
                 softmax_step(u, no{});
                 m_prefetch(ring_u, ring_up1);     // first fragments of M(u+1): V(u) and K(u+1) landed one barrier ago
                 end_s_phase();
                 advance_ring();
             }
-#endif
         }
         for (; u < n_tiles; ++u) iteration(u, yes{});    // diagonal / ragged tiles
         // ---- move on ----

@@ -18,7 +18,7 @@ def main():
     for src in b.HIP_SOURCES:
         o = os.path.join(out_dir, f"{name}_{src[:-4]}.o")
         objs.append(o)
-        procs.append(subprocess.Popen([b.hipcc_path()] + b.HIPCC_FLAGS + flags + ["-I", b.CSRC, "-I", b.INCLUDE, "-c", os.path.join(b.CSRC, src), "-o", o]))
+        procs.append(subprocess.Popen([b.hipcc_path()] + b.HIPCC_FLAGS + b.EXTRA_FLAGS.get(src, []) + flags + ["-I", b.CSRC, "-I", b.INCLUDE, "-c", os.path.join(b.CSRC, src), "-o", o]))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("hipcc failed")
