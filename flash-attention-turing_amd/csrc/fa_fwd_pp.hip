@@ -43,33 +43,15 @@ constexpr float kPpDeferLog2 = 6.0f;
 // 0.90-0.93x time at 8k, 0.96x at 16k, 0.75x at 2k, 0.71x at 512; non-causal and D = 128 unchanged; outputs bit-identical.
 #define FA_PP_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
 
-// A lane-constant value made opaque to the optimiser at the point of use.  Address arithmetic that depends only on the lane id is
-// loop-invariant for the whole kernel; hipcc hoists it out of the item loop and then spills it around the tile loop (dozens of
-// VGPRs for the epilogue / Q staging addresses).  Recomputing it per item costs a few VALU per ~10^5 cycles.
-template <bool ENABLE>
-FA_DEV int opaque_lane_value(int x) {
-    if constexpr (ENABLE) asm volatile("" : "+v"(x));
-    return x;
-}
-
-// One work item = one 256-row query tile of one (batch, head).
-struct FwdItem {
-    int tile, batch, head;
-};
-
-// PERSIST = false: one item per workgroup (grid = items; used for varlen and for shapes whose tiles may hold fewer than two key
-// tiles).  PERSIST = true (fixed-length batches): the grid is one workgroup per CU slot and every workgroup walks a static
-// list of items as ONE continuous stream of key tiles:
-//   * items come in pairs (query tile T-1-j, then j) of one (batch, head): under the causal mask every pair costs the same, so
-//     all workgroups stay level without atomics or a work queue;
-//   * pairs of one head are handed to the 32 workgroups of ONE XCD (block id % 8), which therefore sweep that head's K / V
-//     together and share its tiles through the XCD's L2;
-//   * the K / V rings, the two-group phase offset and the barrier cadence run straight through item boundaries: the last
-//     iterations of an item already DMA the first K / V tiles of the next one, the next item's Q block is parked in LDS (the
-//     staging region, by LDS-DMA) one item ahead, and the boundary matrix phase is [Q' -> registers; pending P*V of the old item;
-//     its epilogue; first QK^T of the new item] - no pipeline drain / refill, no exposed HBM latency, no barrier added;
-//   * the epilogue is wave-local (every wave stages and stores its own 32 rows), so it needs no workgroup barrier either.
-template <typename T, int D, bool CAUSAL, bool PERSIST>
+// One workgroup = one 256-row query tile of one (batch, head).  Two multi-item variants were built and measured in round 2 and are
+// NOT here (the persistent one is in the history at 1c7aadc..3e5f845, disabled): a persistent grid walking a static, XCD-aware item list, and per-workgroup
+// pairs of query tiles (T-1-j, j) for causal balance, both running the K / V rings, the phase offset and the barrier cadence
+// straight through item boundaries (next item's first K / V tiles prefetched by the last iterations, its Q block parked in LDS,
+// boundary matrix phase = [Q' -> registers; pending P*V; epilogue; first QK^T]).  Both were bit-identical to this kernel and both
+// were SLOWER: hipcc gives the tile loop a worse register allocation once it sits inside an item loop (persistent: kernel arguments
+// of the next head stay live across it, loop descriptors get spilled, LDS reads serialise: 1.27-1.7x; pairs: 256 VGPRs + 30
+// spilled, 1.02-1.05x at 4k-16k, 1.26x at causal 1k, and half the grid at 512).  profiles/r2_fwd_pair_mode_ab.log.
+template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_kernel(const FwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
     constexpr int TILEB = kFwdBlockN * ROWB;
@@ -79,7 +61,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
     FA_LDS char* kring = smem;
     FA_LDS char* vring = smem + RING * TILEB;
-    FA_LDS char* stage = smem + RINGB;            // Q block of the NEXT item (LDS-DMA) / O block of the finished item; wave-local rows
+    FA_LDS char* stage = smem + RINGB;            // O block on its way out; every wave touches only its own 32 rows
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,67 +71,42 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     const uint32_t q_rowb = (uint32_t)(p.q.row * 2), k_rowb = (uint32_t)(p.k.row * 2),
                    v_rowb = (uint32_t)(p.v.row * 2), o_rowb = (uint32_t)(p.o.row * 2);
 
-    // ---- item sequence of this workgroup ---------------------------------------------------------------
-    // Everything about an item is recomputed from (tile, batch, head) where it is needed (a handful of scalar instructions at an
-    // item boundary) instead of being carried through the tile loop: the loop is short of scalar registers, not of SALU slots.
-    int seq_i = 0;                                   // position in the workgroup's item sequence
-    auto next_item = [&](FwdItem& it) -> bool {
-        if constexpr (!PERSIST) {
-            if (seq_i++ != 0) return false;
-            int tiles_seq;
-            if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, it.tile, it.batch, it.head, tiles_seq)) return false;
-            if (CAUSAL) it.tile = tiles_seq - 1 - it.tile;      // heaviest (latest) query tiles first
-            return true;
-        } else {
-            const uint32_t NT = p.n_q_tiles, J = (NT + 1) >> 1, n_bh = (uint32_t)(p.b * p.h), G = gridDim.x;
-            for (;;) {
-                const uint32_t i = (uint32_t)seq_i++, e = i & 1u;
-                uint32_t bh, pi;
-                if ((n_bh & 7u) == 0 && (G & 7u) == 0) {            // all pairs of a head on one XCD (block id % 8)
-                    const uint32_t x = blockIdx.x & 7u, jl = (blockIdx.x >> 3) + (i >> 1) * (G >> 3);
-                    if (jl >= (n_bh >> 3) * J) return false;
-                    bh = (jl / J) * 8u + x; pi = jl % J;
-                } else {
-                    const uint32_t jg = blockIdx.x + (i >> 1) * G;
-                    if (jg >= n_bh * J) return false;
-                    bh = jg / J; pi = jg % J;
-                }
-                const uint32_t t_heavy = NT - 1 - pi;
-                if (e == 1 && t_heavy == pi) continue;               // odd tile count: the middle tile is its own pair
-                it.tile = (int)(e == 0 ? t_heavy : pi);
-                it.batch = (int)(bh / (uint32_t)p.h); it.head = (int)(bh % (uint32_t)p.h);
-                return true;
-            }
-        }
-    };
+    // ---- items of this workgroup ------------------------------------------------------------------------
+    int tile, batch, head, tiles_seq;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (CAUSAL) tile = tiles_seq - 1 - tile;            // heaviest (latest) query tiles first
 
     // ---- geometry (wave-uniform) -----------------------------------------------------------------------
-    // sq / sk / row origins: per launch for fixed-length batches, per item for varlen (one item per workgroup there)
     int sq = p.seqlen_q, sk = p.seqlen_k;
     int64_t q_row0 = 0, k_row0 = 0;
     const bool varlen = p.cu_seqlens_q != nullptr;
-    auto q_ptr_of = [&](const FwdItem& it) {
-        return uniform_ptr((const T*)p.q_ptr + (varlen ? 0 : (int64_t)it.batch * p.q.batch) + (q_row0 + it.tile * kFwdBlockM) * p.q.row + (int64_t)it.head * p.q.head);
-    };
-    auto o_ptr_of = [&](const FwdItem& it) {
-        return uniform_ptr((T*)p.o_ptr + (varlen ? 0 : (int64_t)it.batch * p.o.batch) + (q_row0 + it.tile * kFwdBlockM) * p.o.row + (int64_t)it.head * p.o.head);
-    };
-    auto k_srd_of = [&](const FwdItem& it) {
-        const T* b = uniform_ptr((const T*)p.k_ptr + (varlen ? 0 : (int64_t)it.batch * p.k.batch) + k_row0 * p.k.row + (int64_t)(it.head / p.h_ratio) * p.k.head);
-        return make_srd(b, sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
-    };
-    auto v_srd_of = [&](const FwdItem& it) {
-        const T* b = uniform_ptr((const T*)p.v_ptr + (varlen ? 0 : (int64_t)it.batch * p.v.batch) + k_row0 * p.v.row + (int64_t)(it.head / p.h_ratio) * p.v.head);
-        return make_srd(b, sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
-    };
-    auto rows_of = [&](const FwdItem& it) { return min(kFwdBlockM, sq - it.tile * kFwdBlockM); };
+    if (varlen) {
+        const int q_beg = p.cu_seqlens_q[batch], k_beg = p.cu_seqlens_k[batch];
+        // a sequence longer than the declared max_seqlen_q is clamped: the padded LSE row holds max_seqlen_q entries only
+        sq = min(p.cu_seqlens_q[batch + 1] - q_beg, p.seqlen_q);
+        sk = p.cu_seqlens_k[batch + 1] - k_beg;
+        q_row0 = q_beg; k_row0 = k_beg;
+    }
+    if (tile * kFwdBlockM >= sq) return;
+    // row 0 of this (batch, head) in Q / O / LSE: everything an item needs beyond these is its tile index
+    const char* q_bh = (const char*)uniform_ptr((const T*)p.q_ptr + (varlen ? 0 : (int64_t)batch * p.q.batch) + q_row0 * p.q.row + (int64_t)head * p.q.head);
+    char* o_bh = (char*)uniform_ptr((T*)p.o_ptr + (varlen ? 0 : (int64_t)batch * p.o.batch) + q_row0 * p.o.row + (int64_t)head * p.o.head);
+    float* lse_bh = uniform_ptr(p.lse_ptr + ((int64_t)batch * p.h + head) * p.lse_row_stride);
+    const int head_k = head / p.h_ratio;
+    const srd_t k_srd = make_srd(uniform_ptr((const T*)p.k_ptr + (varlen ? 0 : (int64_t)batch * p.k.batch) + k_row0 * p.k.row + (int64_t)head_k * p.k.head),
+                                 sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
+    const srd_t v_srd = make_srd(uniform_ptr((const T*)p.v_ptr + (varlen ? 0 : (int64_t)batch * p.v.batch) + k_row0 * p.v.row + (int64_t)head_k * p.v.head),
+                                 sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
+    auto q_ptr_of = [&](int t) { return (const T*)(q_bh + (uint32_t)(t * kFwdBlockM) * q_rowb); };
+    auto o_ptr_of = [&](int t) { return (T*)(o_bh + (uint32_t)(t * kFwdBlockM) * o_rowb); };
+    auto rows_of = [&](int t) { return min(kFwdBlockM, sq - t * kFwdBlockM); };
     int m0 = 0, delta = 0, n_tiles = 0, n_main = 0;   // of the CURRENT item
-    auto set_current = [&](const FwdItem& it) {
-        m0 = it.tile * kFwdBlockM;
+    auto set_current = [&](int t) {
+        m0 = t * kFwdBlockM;
         delta = sk - sq;
         n_tiles = (sk + kFwdBlockN - 1) / kFwdBlockN;
         if (CAUSAL) {
-            const int max_key = m0 + rows_of(it) - 1 + delta;
+            const int max_key = m0 + rows_of(t) - 1 + delta;
             n_tiles = max_key < 0 ? 0 : min(n_tiles, max_key / kFwdBlockN + 1);
         }
         // Tiles [0, n_main) are fully visible to every row of the workgroup and fully inside the sequence: no mask, no per-wave
@@ -188,40 +145,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                 v_rd[sec][db] = lds_tile_off<D>(4 * hi + 8 * sec + (L >> 2), 4 * db + 2 * g + ((L & 3) >> 1)) + 8 * (L & 1);
     }
 
-    // ---- first item ------------------------------------------------------------------------------------
-    FwdItem cur_it, nxt_it, done_it;                   // `done_it`: the finished item whose last P*V / epilogue is pending
-    if (!next_item(cur_it)) return;
-    if (varlen) {
-        const int q_beg = p.cu_seqlens_q[cur_it.batch], k_beg = p.cu_seqlens_k[cur_it.batch];
-        // a sequence longer than the declared max_seqlen_q is clamped: the padded LSE row holds max_seqlen_q entries only
-        sq = min(p.cu_seqlens_q[cur_it.batch + 1] - q_beg, p.seqlen_q);
-        sk = p.cu_seqlens_k[cur_it.batch + 1] - k_beg;
-        q_row0 = q_beg; k_row0 = k_beg;
-    }
-    if (cur_it.tile * kFwdBlockM >= sq) return;        // (only the one-item-per-workgroup grid can hold an out-of-range tile)
-    set_current(cur_it);
-    bool has_next = false;
-    if constexpr (PERSIST) has_next = next_item(nxt_it);
-    srd_t k_srd = k_srd_of(cur_it), v_srd = v_srd_of(cur_it);
-    srd_t k_srd_n = k_srd, v_srd_n = v_srd;
-    if (has_next) { k_srd_n = k_srd_of(nxt_it); v_srd_n = v_srd_of(nxt_it); }
-
-    // Q block of an item -> this wave's 32 rows of the staging region (8 KiB at d = 128), swizzled like a K tile
-    constexpr int NQP = SLOTS / 2;                     // 1-KiB pieces per wave
-    const uint32_t lds_q0 = lds_addr(stage) + (uint32_t)wave * 32 * ROWB;
-    auto dma_q_block = [&](const FwdItem& it) {
-        const srd_t q_srd = make_srd(q_ptr_of(it), (uint32_t)(rows_of(it) - 1) * q_rowb + ROWB);
-        const int ln = opaque_lane_value<PERSIST>(lane);
-#pragma unroll
-        for (int i = 0; i < NQP; ++i) {
-            const int chunk = i * 64 + ln, row = wave * 32 + chunk / SLOTS, phys = chunk % SLOTS;
-            dma16_to_lds_hidden<false>(q_srd, (uint32_t)row * q_rowb + lds_tile_logical_slot<D>(row, phys) * 16, lds_q0 + i * 1024);
-        }
-    };
+    set_current(tile);
 
     u32x4 qf[KS];
     {
-        const rsrc_t q_rs = make_rsrc(q_ptr_of(cur_it), (uint32_t)(rows_of(cur_it) - 1) * q_rowb + ROWB);
+        const rsrc_t q_rs = make_rsrc(uniform_ptr(q_ptr_of(tile)), (uint32_t)(rows_of(tile) - 1) * q_rowb + ROWB);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = buf_load16(q_rs, (uint32_t)q_row * q_rowb + (2 * ks + hi) * 16);
     }
@@ -232,13 +160,6 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
     float m_run = kNegBig, l_run = 0.f;
-    auto reset_row_state = [&]() {
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-        m_run = kNegBig; l_run = 0.f;
-    };
 
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
     auto dma_k_tile = [&](const srd_t& srd, int t, int slot) {
@@ -250,13 +171,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
     };
 
-    // ---- prologue of the FIRST item: K(0), V(0), K(1) into the rings (past-the-end tiles arrive as zeros) ---------------
+    // ---- prologue: K(0), V(0), K(1) into the rings (past-the-end tiles arrive as zeros) ---------------
     if (n_tiles > 0) {
         dma_k_tile(k_srd, 0, 0);
         dma_v_tile(v_srd, 0, 0);
         dma_k_tile(k_srd, 1, 1);
     }
-    if (has_next) dma_q_block(nxt_it);                 // parked in LDS one item ahead
     // every wave reads rows DMA-ed by the other waves: own pieces landed (vmcnt), THEN the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -339,24 +259,18 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // K(u+2) starts flying at the very END of M(u), after the phase's last LDS read, where the wave would otherwise just wait
     // for its partner at the barrier; V(u+1) at the START of S(u), which reads no LDS.  Previous tenants of the slots, K(u-1) and
     // V(u-2), were last read in M(u-1) of the other group, at least one barrier before the earliest issue.  Both are retired by
-    // the explicit vmcnt(0) that ends S(u).  Past the last tile of the current item the same two calls fetch the FIRST tiles of
-    // the next item (K(0)', K(1)', V(0)'): the key-tile stream, and with it the ring rotation, runs across item boundaries.
+    // the explicit vmcnt(0) that ends S(u).
     auto issue_dma_k = [&](int u) {
         if (u + 2 < n_tiles) dma_k_tile(k_srd, u + 2, ring_um1);
-        else if (PERSIST && has_next) dma_k_tile(k_srd_n, u + 2 - n_tiles, ring_um1);
     };
     auto issue_dma_v = [&](int u) {
         if (u + 1 < n_tiles) dma_v_tile(v_srd, u + 1, ring_up1);
-        else if (PERSIST && has_next) dma_v_tile(v_srd_n, 0, ring_up1);
     };
     auto softmax_step = [&](int u, auto masked) {
         const int n0 = u * kFwdBlockN;
         if constexpr (decltype(masked)::value) {
             const bool need_mask = (n0 + kFwdBlockN > sk) || (CAUSAL && (n0 + kFwdBlockN - 1 > wave_q_lo + delta));
             if (need_mask) {
-                // lane-dependent parts re-derived here (opaque): otherwise 32 key indices per lane are hoisted out of the ITEM loop
-                // and held across the steady-state loop, which then has no registers left to prefetch its LDS fragments
-                const int ln = opaque_lane_value<PERSIST>(lane), hi = ln >> 5, q_row = wave * 32 + (ln & 31);
                 const int lim = CAUSAL ? min(sk - 1, m0 + q_row + delta) : sk - 1;
 #pragma unroll
                 for (int bi = 0; bi < 2; ++bi)
@@ -412,15 +326,15 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    // Epilogue of a finished item, wave-local: normalise, round, stage this wave's 32 rows in LDS, store them as whole rows.
-    // No workgroup barrier: a wave reads back only what it wrote itself.
-    auto epilogue = [&](const FwdItem& it) {
-        const int rows_here = rows_of(it);
-        const int ln = opaque_lane_value<PERSIST>(lane), q_row = wave * 32 + (ln & 31), hi = ln >> 5;     // shadows: not hoistable
+    // Epilogue, wave-local: normalise, round, stage this wave's 32 rows in LDS (own region, not the rings: the other group may
+    // still be reading those), store them as whole rows.  No workgroup barrier: a wave reads back only what it wrote itself.
+    auto epilogue = [&](int t) {
+        const int rows_here = rows_of(t);
+        const int ln = lane;
         const float l_tot = sum_both_halves(l_run);
         const float inv = l_tot > 0.f ? fast_rcp(l_tot) : 0.f;
         const float lse = l_tot > 0.f ? (m_run * c + fast_log2(l_tot)) * kLn2 : 0.f;
-        if (hi == 0 && q_row < rows_here) p.lse_ptr[((int64_t)it.batch * p.h + it.head) * p.lse_row_stride + it.tile * kFwdBlockM + q_row] = lse;
+        if (hi == 0 && q_row < rows_here) lse_bh[t * kFwdBlockM + q_row] = lse;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -430,7 +344,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                 w.y = LP<T>::pack2(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
                 lds_write8(stage, lds_tile_off<D>(q_row, 4 * db + g4) + 8 * hi, w);
             }
-        const rsrc_t o_rs = make_rsrc(o_ptr_of(it), (uint32_t)(rows_here - 1) * o_rowb + ROWB);
+        const rsrc_t o_rs = make_rsrc(uniform_ptr(o_ptr_of(t)), (uint32_t)(rows_here - 1) * o_rowb + ROWB);
         constexpr int O_CHUNKS = (32 * SLOTS) / 64;
 #pragma unroll
         for (int i = 0; i < O_CHUNKS; ++i) {
@@ -442,30 +356,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     using no = std::integral_constant<bool, false>;
 
     bool prev_active = false;                         // does this wave hold a P tile whose P*V is pending?
-    bool pending = false;                             // is there a finished item (`done`) whose last P*V and epilogue are pending?
-    // One iteration = matrix phase M(u) | barrier | softmax phase S(u) | vmcnt(0), barrier.  u = 0 is also the item boundary.
+    // One iteration = matrix phase M(u) | barrier | softmax phase S(u) | vmcnt(0), barrier.
     auto iteration = [&](int u, auto masked) {
         bool active = true;
         if constexpr (decltype(masked)::value) active = !CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta);
-        if (u == 0 && pending) {
-            // boundary: the new item's Q block leaves the staging region first (LDS operations of a wave execute in order, so the
-            // epilogue's writes to the same rows cannot overtake these reads), then the old item is finished in place
-            {
-                const int ln = opaque_lane_value<PERSIST>(lane);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) qf[ks] = lds_read16(stage, lds_tile_off<D>(wave * 32 + (ln & 31), 2 * ks + (ln >> 5)));
-            }
-            if (prev_active) pv_step();
-            epilogue(done_it);
-            reset_row_state();
-            pending = false;
-            if (has_next) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the epilogue's staging reads have returned
-                dma_q_block(nxt_it);
-            }
-        } else if (prev_active) {
-            pv_step();
-        }
+        if (prev_active) pv_step();
         if (active) qk_step();
         issue_dma_k(u);
         __syncthreads();
@@ -476,87 +371,45 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         advance_ring();
     };
 
-    for (;;) {
-        // ---- all key tiles of the current item (persistent grids only run shapes whose tiles all hold >= 2 key tiles) ----
-        int u = 0;
-        if (n_main > 0) {
-            iteration(0, no{});
-            if (n_main > 1) m_prefetch(ring_um1, ring_u);
-            for (u = 1; u < n_main; ++u) {        // steady state: branch-free
-                m_phase();
-                __syncthreads();
-                issue_dma_k(u);
-                issue_dma_v(u);
-                softmax_step(u, no{});
-                m_prefetch(ring_u, ring_up1);     // first fragments of M(u+1): V(u) and K(u+1) landed one barrier ago
-                end_s_phase();
-                advance_ring();
-            }
+    int u = 0;
+    if (n_main > 0) {
+        iteration(0, no{});
+        if (n_main > 1) m_prefetch(ring_um1, ring_u);
+        for (u = 1; u < n_main; ++u) {            // steady state: branch-free
+            m_phase();
+            __syncthreads();
+            issue_dma_k(u);
+            issue_dma_v(u);
+            softmax_step(u, no{});
+            m_prefetch(ring_u, ring_up1);         // first fragments of M(u+1): V(u) and K(u+1) landed one barrier ago
+            end_s_phase();
+            advance_ring();
         }
-        for (; u < n_tiles; ++u) iteration(u, yes{});    // diagonal / ragged tiles
-        // ---- move on ----
-        done_it = cur_it;
-        pending = true;
-        if (!(PERSIST && has_next)) break;
-        cur_it = nxt_it;
-        k_srd = k_srd_n; v_srd = v_srd_n;
-        set_current(cur_it);
-        wave_q_lo = m0 + wave * 32; wave_q_hi = wave_q_lo + 31;
-        has_next = next_item(nxt_it);
-        if (has_next) { k_srd_n = k_srd_of(nxt_it); v_srd_n = v_srd_of(nxt_it); }
     }
-    // ---- drain: the last item's pending P*V and its epilogue ----
+    for (; u < n_tiles; ++u) iteration(u, yes{});        // diagonal / ragged tiles
+    // ---- drain: the last P*V and the epilogue ----
     if (prev_active) pv_step();
-    epilogue(done_it);
+    epilogue(tile);
     if (group == 0) __syncthreads();          // group A waits for B's last phase (equal barrier counts)
 }
 
 
-template <typename T, int D, bool PERSIST>
+template <typename T, int D>
 static hipError_t launch_pp_t(const FwdKernelParams& kp, uint32_t grid, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
-    if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, PERSIST>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
-    else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, PERSIST>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
     return hipGetLastError();
 }
 
 const char* fwd_kernel_name(int) { return "fa_fwd_pp_kernel"; }
 
-// Workgroups the persistent grid may hold at once = CUs x workgroups per CU (D = 128: one 160-KiB workgroup; D = 64: two).
-static uint32_t persistent_slots(int d) {
-    static int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    return (uint32_t)cus * (d == 64 ? 2u : 1u);
-}
-
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
-    // Persistent stream: fixed-length batches in which EVERY query tile holds at least two key tiles (the cross-item prefetch looks
-    // two tiles ahead) and with more items than workgroup slots (otherwise there is nothing to stream across).
-    const uint64_t items = (uint64_t)kp.n_q_tiles * (uint64_t)kp.b * (uint64_t)kp.h;
-    const uint32_t slots = persistent_slots(kp.d);
-    // kEnablePersistent = false: the persistent instances are correct (bit-identical outputs, GPU-tested) but hipcc currently starves
-    // their steady-state loop of registers (boundary-only kernel arguments stay live across it), which serialises its LDS reads;
-    // they are not instantiated until that is fixed (forward).
-    constexpr bool kEnablePersistent = false;
-    if constexpr (kEnablePersistent) {
-        const uint64_t items = (uint64_t)kp.n_q_tiles * (uint64_t)kp.b * (uint64_t)kp.h;
-        const uint32_t slots = persistent_slots(kp.d);
-        const bool persist = kp.cu_seqlens_q == nullptr && kp.seqlen_k >= 2 * kFwdBlockN && (!kp.is_causal || kp.seqlen_k >= kp.seqlen_q) && items > slots;
-        if (persist) {
-            const uint64_t pairs = (uint64_t)((kp.n_q_tiles + 1) / 2) * (uint64_t)kp.b * (uint64_t)kp.h;
-            const uint32_t grid = (uint32_t)(pairs < slots ? pairs : slots);
-            if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128, kEnablePersistent>(kp, grid, stream) : launch_pp_t<_Float16, 64, kEnablePersistent>(kp, grid, stream);
-            return kp.d == 128 ? launch_pp_t<__bf16, 128, kEnablePersistent>(kp, grid, stream) : launch_pp_t<__bf16, 64, kEnablePersistent>(kp, grid, stream);
-        }
-    }
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
-    if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128, false>(kp, grid, stream) : launch_pp_t<_Float16, 64, false>(kp, grid, stream);
-    return kp.d == 128 ? launch_pp_t<__bf16, 128, false>(kp, grid, stream) : launch_pp_t<__bf16, 64, false>(kp, grid, stream);
+    if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, grid, stream) : launch_pp_t<_Float16, 64>(kp, grid, stream);
+    return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, grid, stream) : launch_pp_t<__bf16, 64>(kp, grid, stream);
 }
 
 }  // namespace fa
