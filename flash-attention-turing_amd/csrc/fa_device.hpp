@@ -11,6 +11,8 @@
 // B operand (see "k-slot" helpers below) with no LDS round trip and no cross-lane moves.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 namespace fa {
@@ -222,6 +224,16 @@ FA_DEV float sum_both_halves(float x) {
 FA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 FA_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 FA_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Compile-time loop: f(integral_constant<int, I>) for I in [B, E).  Arrays indexed this way are scalarised before any loop pass
+// runs (a `#pragma unroll` loop over a local array can leave it in scratch when the unroller gets to it late).
+template <int B, int E, typename F>
+FA_DEV void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // Row index (0..31) inside a 32x32 C tile owned by accumulator register r of this lane.
 FA_DEV int c_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

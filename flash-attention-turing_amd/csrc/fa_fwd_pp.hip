@@ -42,6 +42,9 @@ constexpr float kPpDeferLog2 = 6.0f;
 // spill and no extra instruction in any loop; interleaved A/B, causal forward (profiles/r1_fwd_d64_occupancy_ab.log):
 // 0.90-0.93x time at 8k, 0.96x at 16k, 0.75x at 2k, 0.71x at 512; non-causal and D = 128 unchanged; outputs bit-identical.
 #define FA_PP_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+#ifndef FA_PP_OPTIMISTIC
+#define FA_PP_OPTIMISTIC(D, CAUSAL) ((D) == 128 || !(CAUSAL))      // D = 64 causal: the extra path does not fit its 128 registers
+#endif
 
 // One workgroup = one 256-row query tile of one (batch, head).  Two multi-item variants were built and measured in round 2 and are
 // NOT here (the persistent one is in the history at 1c7aadc..3e5f845, disabled): a persistent grid walking a static, XCD-aware item list, and per-workgroup
@@ -97,11 +100,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                                  sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
     const srd_t v_srd = make_srd(uniform_ptr((const T*)p.v_ptr + (varlen ? 0 : (int64_t)batch * p.v.batch) + k_row0 * p.v.row + (int64_t)head_k * p.v.head),
                                  sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
-    auto q_ptr_of = [&](int t) { return (const T*)(q_bh + (uint32_t)(t * kFwdBlockM) * q_rowb); };
-    auto o_ptr_of = [&](int t) { return (T*)(o_bh + (uint32_t)(t * kFwdBlockM) * o_rowb); };
-    auto rows_of = [&](int t) { return min(kFwdBlockM, sq - t * kFwdBlockM); };
+    auto q_ptr_of = [&](int t) __attribute__((always_inline)) { return (const T*)(q_bh + (uint32_t)(t * kFwdBlockM) * q_rowb); };
+    auto o_ptr_of = [&](int t) __attribute__((always_inline)) { return (T*)(o_bh + (uint32_t)(t * kFwdBlockM) * o_rowb); };
+    auto rows_of = [&](int t) __attribute__((always_inline)) { return min(kFwdBlockM, sq - t * kFwdBlockM); };
     int m0 = 0, delta = 0, n_tiles = 0, n_main = 0;   // of the CURRENT item
-    auto set_current = [&](int t) {
+    auto set_current = [&](int t) __attribute__((always_inline)) {
         m0 = t * kFwdBlockM;
         delta = sk - sq;
         n_tiles = (sk + kFwdBlockN - 1) / kFwdBlockN;
@@ -162,11 +165,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     float m_run = kNegBig, l_run = 0.f;
 
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
-    auto dma_k_tile = [&](const srd_t& srd, int t, int slot) {
+    auto dma_k_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * k_rowb + dma_goff_k[i], lds_k0 + slot * TILEB + i * 1024);
     };
-    auto dma_v_tile = [&](const srd_t& srd, int t, int slot) {
+    auto dma_v_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
     };
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     int wave_q_lo = m0 + wave * 32, wave_q_hi = wave_q_lo + 31;
 
     // ---- phase bodies ---------------------------------------------------------------------------
-    auto pv_step = [&]() {                            // O^T += V(u-1)^T P(u-1)^T
+    auto pv_step = [&]() __attribute__((always_inline)) {                            // O^T += V(u-1)^T P(u-1)^T
         FA_LDS char* vbuf = vring + ring_um1 * TILEB;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                 oacc[db] = LP<T>::mfma(vf, pf[ts], oacc[db]);
             }
     };
-    auto qk_step = [&]() {                            // S(u)^T = K(u) Q^T
+    auto qk_step = [&]() __attribute__((always_inline)) {                            // S(u)^T = K(u) Q^T
         FA_LDS char* kbuf = kring + ring_u * TILEB;
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi) {
@@ -218,8 +221,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // phase starts on an MFMA instead of on an LDS round trip.  Measured with per-phase s_memtime stamps (tools/phase_timing.py,
     // profiles/r2_fwd_phase_timing.log): the period of the ping-pong is the SUM of the two groups' matrix phases (the softmax
     // phases hide behind them), and a matrix phase took 1270 cycles for 1024 cycles of MFMA issue.
+    constexpr bool kOptimistic = FA_PP_OPTIMISTIC(D, CAUSAL);
     constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? 2 : 4;      // fragments in flight; D = 64 has 128 VGPRs only
-    auto m_frag = [&](int j, int slot_v, int slot_k) -> u32x4 {
+    auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
         if (j < NPV) {
             const int db = j / 4, ts = j % 4;
             FA_LDS char* vbuf = vring + slot_v * TILEB;
@@ -230,43 +234,61 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         const int i = j - NPV, ks = i / 2, bi = i % 2;
         return lds_read16(kring + slot_k * TILEB, k_rd[ks] + bi * 32 * ROWB);
     };
+    // read bases with the ring origin folded in and hidden from the compiler: with compile-time ring slots every fragment read is
+    // base + 16-bit immediate (slot * 16 KiB + row block), no address arithmetic left in the loop
+    uint32_t k_abs[KS], v_abs[2][DB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { k_abs[ks] = lds_addr(kring) + k_rd[ks]; asm volatile("" : "+v"(k_abs[ks])); }
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { v_abs[sec][db] = lds_addr(vring) + v_rd[sec][db]; asm volatile("" : "+v"(v_abs[sec][db])); }
+    auto m_frag_c = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
+        if (j < NPV) {
+            const int db = j / 4, ts = j % 4;
+            const u32x2 a0 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_abs[0][db], slot_v * TILEB + ts * 16 * ROWB);
+            const u32x2 a1 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_abs[1][db], slot_v * TILEB + ts * 16 * ROWB);
+            return u32x4{a0.x, a0.y, a1.x, a1.y};
+        }
+        const int i = j - NPV, ks = i / 2, bi = i % 2;
+        return lds_read16((const FA_LDS char*)(uintptr_t)k_abs[ks], slot_k * TILEB + bi * 32 * ROWB);
+    };
     u32x4 pre[PF];
-    auto m_prefetch = [&](int slot_v, int slot_k) {
+    auto m_prefetch = [&](int slot_v, int slot_k) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) pre[j] = m_frag(j, slot_v, slot_k);
     };
-    auto m_phase = [&]() {
+    auto m_phase = [&]() __attribute__((always_inline)) {
         u32x4 fr[NST];
-#pragma unroll
-        for (int j = 0; j < PF; ++j) fr[j] = pre[j];
-#pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            if (j + PF < NST) fr[j + PF] = m_frag(j + PF, ring_um1, ring_u);
+        static_for<0, PF>([&](auto jc) { fr[decltype(jc)::value] = pre[decltype(jc)::value]; });
+        static_for<0, NST>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + PF < NST) fr[j + PF] = m_frag(j + PF, ring_um1, ring_u);
             __builtin_amdgcn_sched_barrier(0);
-            if (j < NPV) {
+            if constexpr (j < NPV) {
                 oacc[j / 4] = LP<T>::mfma(fr[j], pf[j % 4], oacc[j / 4]);
             } else {
-                const int i = j - NPV, ks = i / 2, bi = i % 2;
-                if (ks == 0) {
+                constexpr int i = j - NPV, ks = i / 2, bi = i % 2;
+                if constexpr (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
                 }
                 sacc[bi] = LP<T>::mfma(fr[j], qf[ks], sacc[bi]);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
     // K(u+2) starts flying at the very END of M(u), after the phase's last LDS read, where the wave would otherwise just wait
     // for its partner at the barrier; V(u+1) at the START of S(u), which reads no LDS.  Previous tenants of the slots, K(u-1) and
     // V(u-2), were last read in M(u-1) of the other group, at least one barrier before the earliest issue.  Both are retired by
     // the explicit vmcnt(0) that ends S(u).
-    auto issue_dma_k = [&](int u) {
+    auto issue_dma_k = [&](int u) __attribute__((always_inline)) {
         if (u + 2 < n_tiles) dma_k_tile(k_srd, u + 2, ring_um1);
     };
-    auto issue_dma_v = [&](int u) {
+    auto issue_dma_v = [&](int u) __attribute__((always_inline)) {
         if (u + 1 < n_tiles) dma_v_tile(v_srd, u + 1, ring_up1);
     };
-    auto softmax_step = [&](int u, auto masked) {
+    auto softmax_step = [&](int u, auto masked) __attribute__((always_inline)) {
         const int n0 = u * kFwdBlockN;
         if constexpr (decltype(masked)::value) {
             const bool need_mask = (n0 + kFwdBlockN > sk) || (CAUSAL && (n0 + kFwdBlockN - 1 > wave_q_lo + delta));
@@ -279,6 +301,27 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                         const int key = n0 + 32 * bi + c_row(r, hi);
                         sacc[bi][r] = key <= lim ? sacc[bi][r] : -INFINITY;
                     }
+            }
+        }
+        if constexpr (kOptimistic && !decltype(masked)::value) {
+            // Optimistic pass: exponentials against the running max as it stands, no row-max reduction.  A lane whose 32 terms sum to
+            // <= 2^kPpDeferLog2 holds no term above that bound (the same bound the deferred-max rule below guarantees), so P, l and O
+            // stay in range and the pass stands; otherwise (Inf and NaN included) the wave falls through to the exact path, which
+            // still has the scores.
+            const float mc0 = m_run * c;
+            float ps = 0.f;
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc0)), p1 = fast_exp2(__builtin_fmaf(sacc[bi][r + 1], c, -mc0));
+                    ps += p0;
+                    ps += p1;
+                    pf[2 * bi + (r >> 3)][(r & 7) >> 1] = LP<T>::pack2(p0, p1);      // = pack_c_half word by word
+                }
+            if (__builtin_amdgcn_ballot_w64(!(ps <= 64.0f)) == 0) {
+                l_run += ps;
+                return;
             }
         }
         float mx = sacc[0][0];
@@ -312,23 +355,23 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                     sacc[bi][r] = pv;
                 }
         }
-        l_run += psum;
 #pragma unroll
         for (int ts = 0; ts < 4; ++ts) pf[ts] = pack_c_half<T>(sacc[ts >> 1], ts & 1);
+        l_run += psum;
     };
-    auto advance_ring = [&]() {
+    auto advance_ring = [&]() __attribute__((always_inline)) {
         ring_um1 = ring_u;
         ring_u = ring_up1;
         ring_up1 = ring_up1 == 2 ? 0 : ring_up1 + 1;
     };
     // every S phase ends with: this wave's LDS-DMA pieces have landed (vmcnt) -> workgroup barrier
-    auto end_s_phase = [&]() {
+    auto end_s_phase = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
     // Epilogue, wave-local: normalise, round, stage this wave's 32 rows in LDS (own region, not the rings: the other group may
     // still be reading those), store them as whole rows.  No workgroup barrier: a wave reads back only what it wrote itself.
-    auto epilogue = [&](int t) {
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int rows_here = rows_of(t);
         const int ln = lane;
         const float l_tot = sum_both_halves(l_run);
@@ -357,7 +400,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 
     bool prev_active = false;                         // does this wave hold a P tile whose P*V is pending?
     // One iteration = matrix phase M(u) | barrier | softmax phase S(u) | vmcnt(0), barrier.
-    auto iteration = [&](int u, auto masked) {
+    auto iteration = [&](int u, auto masked) __attribute__((always_inline)) {
         bool active = true;
         if constexpr (decltype(masked)::value) active = !CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta);
         if (prev_active) pv_step();
@@ -375,7 +418,49 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     if (n_main > 0) {
         iteration(0, no{});
         if (n_main > 1) m_prefetch(ring_um1, ring_u);
-        for (u = 1; u < n_main; ++u) {            // steady state: branch-free
+        // ring slot of tile u is u % 3: three steps per trip make every slot a constant
+        auto step_c = [&](int uu, auto um1, auto u0, auto up1) __attribute__((always_inline)) {
+            constexpr int S_UM1 = decltype(um1)::value, S_U = decltype(u0)::value, S_UP1 = decltype(up1)::value;
+            {
+                u32x4 fr[NST];
+                static_for<0, PF>([&](auto jc) { fr[decltype(jc)::value] = pre[decltype(jc)::value]; });
+                static_for<0, NST>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j + PF < NST) fr[j + PF] = m_frag_c(j + PF, S_UM1, S_U);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (j < NPV) {
+                        oacc[j / 4] = LP<T>::mfma(fr[j], pf[j % 4], oacc[j / 4]);
+                    } else {
+                        constexpr int i = j - NPV, ks = i / 2, bi = i % 2;
+                        if constexpr (ks == 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
+                        }
+                        sacc[bi] = LP<T>::mfma(fr[j], qf[ks], sacc[bi]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            __syncthreads();
+            if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
+            if (uu + 1 < n_tiles) dma_v_tile(v_srd, uu + 1, S_UP1);
+            softmax_step(uu, no{});
+#pragma unroll
+            for (int j = 0; j < PF; ++j) pre[j] = m_frag_c(j, S_U, S_UP1);
+            end_s_phase();
+        };
+        using i0 = std::integral_constant<int, 0>;
+        using i1 = std::integral_constant<int, 1>;
+        using i2 = std::integral_constant<int, 2>;
+        u = 1;
+        if constexpr (D == 128) {                 // (D = 64 runs two workgroups per CU on 128 registers: no room for the extra bases)
+            for (; u + 3 <= n_main; u += 3) {
+                step_c(u, i0{}, i1{}, i2{});
+                step_c(u + 1, i1{}, i2{}, i0{});
+                step_c(u + 2, i2{}, i0{}, i1{});
+            }
+        }
+        for (; u < n_main; ++u) {                 // the last one or two steady-state tiles (all of them for D = 64)
             m_phase();
             __syncthreads();
             issue_dma_k(u);

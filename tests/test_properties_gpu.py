@@ -362,3 +362,56 @@ def test_identity_inputs_analytic_known_answer(gpu, d, causal):
         eo, el = expect(sq, sk, vn[cu_k[i]:cu_k[i + 1]])
         U.assert_close(o[cu_q[i]:cu_q[i + 1]].float().cpu().numpy(), eo, "fp16", f"O identity varlen seq {i}")
         assert np.abs(lse[i, :, :sq].cpu().numpy() - el).max() <= U.LSE_TOL, ("varlen", i)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("ramp", [3.0, 0.02, -3.0])
+def test_running_max_rising_along_the_key_axis(gpu, d, dtype, ramp):
+    """The steady-state softmax of the forward first exponentiates against the running max AS IT STANDS and only falls back to the
+    exact max / rescale path when a lane's partial row sum exceeds 2^6 (fa_fwd_pp.hip).  Scores that keep rising along the key
+    axis force that fallback on every interior tile (ramp 3: each 64-key tile tops the last by e^192 in probability; ramp 0.02:
+    the max creeps up so the deferred rescale triggers every few tiles); ramp -3 never triggers it after tile 0.  All must match
+    fp32 math, forward and backward (the backward recomputes P from the LSE the forward wrote)."""
+    import flash_attn_turing as F
+
+    dt = U.torch_dtype(dtype)
+    b, s, h = 1, 1536, 2
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    q = torch.randn(b, s, h, d, generator=gen) * 0.5
+    k = torch.randn(b, s, h, d, generator=gen) * 0.5
+    # add a component along one fixed direction: q has +1 there, k has ramp * key_index * sqrt(d) / d -> score += ramp * j / ... scaled
+    u = torch.zeros(d); u[0] = 1.0
+    q = q + 4.0 * u
+    k = k + (ramp * torch.arange(s).float() * (d ** 0.5) / 4.0 / 64.0).view(1, s, 1, 1) * u
+    v = torch.randn(b, s, h, d, generator=gen)
+    do = torch.randn(b, s, h, d, generator=gen)
+    q, k, v, do = (x.to(gpu, dt) for x in (q, k, v, do))
+    for causal in (False, True):
+        o, lse = F.fwd(q, k, v, causal)
+        dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
+        o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, causal)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        assert ((lse - lse_r).abs() / lse_r.abs().clamp_min(1.0)).max().item() <= 1e-4
+        U.assert_close(o.float().cpu().numpy(), o_r.cpu().numpy(), dtype, f"O ramp {ramp}", scale=2.0)
+        for name, x, r in (("dQ", dq, dq_r), ("dK", dk, dk_r), ("dV", dv, dv_r)):
+            assert torch.isfinite(x).all()
+            U.assert_close(x.float().cpu().numpy(), r.cpu().numpy(), dtype, f"{name} ramp {ramp}", scale=4.0)
+
+
+def test_nonfinite_scores_propagate_like_fp32_math(gpu):
+    """Inf / NaN in the inputs: the optimistic pass must hand such tiles to the exact path (its `sum <= 2^6` test fails for
+    both) instead of looping or silently dropping them; rows without a non-finite score are unaffected."""
+    import flash_attn_turing as F
+
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    q = torch.randn(1, 512, 1, 128, generator=gen).to(gpu, torch.float16)
+    k = torch.randn(1, 1024, 1, 128, generator=gen).to(gpu, torch.float16)
+    v = torch.randn(1, 1024, 1, 128, generator=gen).to(gpu, torch.float16)
+    q2 = q.clone()
+    q2[0, 7, 0, 3] = float("nan")          # one query row sees NaN scores everywhere
+    o, lse = F.fwd(q2, k, v, False)
+    o_ref, lse_ref = F.fwd(q, k, v, False)
+    assert torch.isnan(o[0, 7]).all() and torch.isnan(lse[0, 0, 7])
+    keep = torch.ones(512, dtype=torch.bool, device=gpu); keep[7] = False
+    assert torch.equal(o[0, keep], o_ref[0, keep]) and torch.equal(lse[0, 0, keep], lse_ref[0, 0, keep])

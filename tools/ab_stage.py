@@ -32,7 +32,7 @@ CONFIGS = {
 
 
 def load(path):
-    L = ctypes.CDLL(path)
+    L = ctypes.CDLL(os.path.abspath(path))
     vp = ctypes.c_void_p
     L.fa_run_mha_fwd.argtypes = [ctypes.POINTER(capi.FwdParams), vp]
     L.fa_run_mha_bwd.argtypes = [ctypes.POINTER(capi.BwdParams), vp]
@@ -100,7 +100,9 @@ def main():
                 med = statistics.median(ts)
                 whole = stage in ("dq", "dkdv") and not hasattr(libs[n], "fa_bwd_dq")
                 same = (not whole) and all(torch.equal(x, y) for x, y in zip(outs[na], outs[n])) if not (stage in ("dq", "dkdv") and not hasattr(libs[na], "fa_bwd_dq")) else None
-                print(f"{cname:26s} {stage:5s} {n:28s} {med:8.3f} ms (min {min(ts):8.3f}) {fl / med / 1e9:6.0f} TF{' [whole bwd]' if whole else ''}  vs A {med / ma:6.4f}  same bits: {same}", flush=True)
+                dmax = max((x.float() - y.float()).abs().max().item() for x, y in zip(outs[na], outs[n])) if (same is False) else 0.0
+                print(f"{cname:26s} {stage:5s} {n:28s} {med:8.3f} ms (min {min(ts):8.3f}) {fl / med / 1e9:6.0f} TF{' [whole bwd]' if whole else ''}  vs A {med / ma:6.4f}  same bits: {same}"
+                      + (f"  max|diff| {dmax:.2e}" if same is False else ""), flush=True)
 
 
 if __name__ == "__main__":
