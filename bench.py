@@ -367,6 +367,7 @@ def bwd_rooflines(torch, capi, et, causal, b, s, h, d):
     HIP events through its stage-level C-ABI entry point.  `executed` FLOPs include the S / dP recomputation (6 and 8 x sq*sk*d
     per head); the algorithmic backward FLOPs (2.5 x forward) are what `bwd_tflops` uses."""
     p = capi.bwd_params(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"], et["dv"], et["dsum"], causal)
+    ws = capi.attach_workspace(p, et["q"])      # noqa: F841  (dK/dV scratch for GQA / MQA shapes; None at the MHA bench shapes)
     pair = b * h * float(s) * s * (0.5 if causal else 1.0)
     out = {}
     for name, kern, flop_mult in (("dot_do_o", "fa_bwd_dot_do_o_kernel", 0), ("dq", "fa_bwd_dq_kernel", 6), ("dkdv", "fa_bwd_dkdv_kernel", 8)):

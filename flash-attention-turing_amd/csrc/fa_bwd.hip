@@ -87,6 +87,9 @@ template <typename T, int D, bool CAUSAL>
 // 0.80-0.90x time, dQ alone 0.90-0.98x, both 0.78-0.83x on every D = 64 shape (8k / 2k / 512, causal or not, GQA); D = 128
 // unchanged (its registers and LDS allow one workgroup per CU only).
 #define FA_DQ_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+#ifndef FA_DQ_NO_UNROLL
+#define FA_DQ_NO_UNROLL 0
+#endif
 #define FA_KV_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
 __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
@@ -188,6 +191,12 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
         dsum = p.dsum_ptr[stat_off + q_row];
     }
     const float c = p.scale_log2e;
+    // D = 128: a loop-invariant block of -D_i feeds the first dP MFMA as its C operand, so dP - D costs no VALU (16 registers; the
+    // D = 64 instance runs on 128 registers and has no room for it)
+    constexpr bool kDpFromMinusD = D == 128;
+    f32x16 negd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negd[r] = -dsum;
 
     f32x16 dqacc[DB];
 #pragma unroll
@@ -203,28 +212,30 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
     asm volatile("" : "+v"(lse2), "+v"(dsum));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    for (int t = 0; t < n_tiles; ++t) {
+    // One key tile.  At D = 128 the loop below runs two tiles per trip, the ring slot is then a compile-time constant and every
+    // LDS fragment read is base register + immediate (18 VALU address adds fewer per tile).
+    auto tile_body = [&](int t, const int BUF) __attribute__((always_inline)) {
         const int n0 = t * kDqBlockN;
-        FA_LDS char* kbuf = smem + (t & 1) * TILEB;
-        FA_LDS char* vbuf = smem + 2 * TILEB + (t & 1) * TILEB;
-        __syncthreads();      // tile t is in LDS (every wave waited for its pieces); buffer (t+1)&1 is free again
-        if (t + 1 < n_tiles) dma_tiles(t + 1, (t + 1) & 1);
+        FA_LDS char* kbuf = smem + BUF * TILEB;
+        FA_LDS char* vbuf = smem + 2 * TILEB + BUF * TILEB;
+        __syncthreads();      // tile t is in LDS (every wave waited for its pieces); the other buffer is free again
+        if (t + 1 < n_tiles) dma_tiles(t + 1, BUF ^ 1);
         const bool wave_active = !CAUSAL || (n0 <= wave_q_hi + delta);
         if (wave_active) {
             // Masking is 2 VALU per score element (compare with an immediate + select), not 4: the key index of
             // element (bi, r) is n0 + 32*bi + (r&3) + 8*(r>>2) + 4*hi, so everything lane- or tile-dependent
-            // (n0, hi, the causal / sk limit, and whether this tile needs a mask at all) is folded ONCE per tile
-            // into `lim_loc`; per element only the compile-time constant 32*bi + (r&3) + 8*(r>>2) is compared.
-            // (Two tile bodies behind a scalar branch remove the mask entirely from interior tiles but push the
-            // D=128 kernel from 233 to 256 VGPRs + 97 spills -- measured in the ISA, not shipped.)
+            // (n0, hi, the causal / sk limit) is folded ONCE per tile into `lim_loc`; per element only the compile-time
+            // constant 32*bi + (r&3) + 8*(r>>2) is compared.  The selects sit behind a wave-uniform branch, so interior
+            // tiles pay nothing: 12-17 % of the kernel (profiles/r2_bwd_valu_trims_ab.log).  (Two whole tile bodies behind
+            // a branch spilled; a branch around the 32 selects alone does not.)
             const bool need_mask = (n0 + kDqBlockN > sk) || (CAUSAL && (n0 + kDqBlockN - 1 > wave_q_lo + delta));
             const int lim = CAUSAL ? min(sk - 1, m0 + q_row + delta) : sk - 1;
-            const int lim_loc = need_mask ? lim - n0 - 4 * hi : 0x7fffffff;
+            const int lim_loc = lim - n0 - 4 * hi;
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi) {           // two 32-key halves, keeps S/dP at 16+16 regs
                 f32x16 sacc, dpacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = kDpFromMinusD ? negd[r] : 0.f; }   // dP chain from -D: dP - D comes out of the MFMAs
                 // S^T and dP^T chains interleaved: consecutive MFMAs never share an accumulator; per-chain order unchanged
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -234,11 +245,25 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
                     dpacc = LP<T>::mfma(vf, dof[ks], dpacc);       // dP^T = V dO^T
                 }
                 // P = exp(s*scale - LSE) (flash_bwd_kernel.h:474), dS = P * (dP - D) (:490)
+                if constexpr (D == 128) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -lse2));
-                    pv = (32 * bi + (r & 3) + 8 * (r >> 2)) <= lim_loc ? pv : 0.f;
-                    sacc[r] = pv * (dpacc[r] - dsum);
+                    for (int r = 0; r < 16; ++r) sacc[r] = fast_exp2(__builtin_fmaf(sacc[r], c, -lse2));
+                    if (need_mask) {                                // wave-uniform branch: interior tiles skip the 2 VALU per element
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[r] = (32 * bi + (r & 3) + 8 * (r >> 2)) <= lim_loc ? sacc[r] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[r] = sacc[r] * dpacc[r];
+                } else {
+                    // D = 64 (128 registers, two workgroups per CU): the branch and the -D block both cost spills there (measured
+                    // +15-19 %); it keeps the select on every tile, the limit opened wide when the tile needs no mask
+                    const int ll = need_mask ? lim_loc : 0x7fffffff;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float pv = fast_exp2(__builtin_fmaf(sacc[r], c, -lse2));
+                        pv = (32 * bi + (r & 3) + 8 * (r >> 2)) <= ll ? pv : 0.f;
+                        sacc[r] = pv * (dpacc[r] - dsum);
+                    }
                 }
                 // dQ^T (D x 32 queries) += K^T (D x 32 keys) * dS^T (32 keys x 32 queries)
 #pragma unroll
@@ -256,6 +281,18 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
+    };
+    {
+        int t = 0;
+        if constexpr (D == 128 && !FA_DQ_NO_UNROLL) {
+            for (; t + 2 <= n_tiles; t += 2) {
+                tile_body(t, 0);
+                tile_body(t + 1, 1);
+            }
+            if (t < n_tiles) tile_body(t, 0);
+        } else {                                  // D = 64 runs on 128 registers: one copy of the body, run-time slot
+            for (; t < n_tiles; ++t) tile_body(t, t & 1);
+        }
     }
 
     // epilogue: dQ *= scale (flash_bwd_kernel.h:765), round, stage through LDS, whole-row stores
@@ -314,8 +351,13 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb = wave & 3, qh = wave >> 2;             // key block / q-half of this wave
 
-    int tile, batch, head_k, tiles_seq;     // tile = 128-key block of this sequence (compact varlen grid: looked up in cu_seqlens_k)
-    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k, tile, batch, head_k, tiles_seq)) return;
+    int tile, batch, vhead, tiles_seq;      // tile = 128-key block of this sequence (compact varlen grid: looked up in cu_seqlens_k)
+    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq)) return;
+    // Few KV heads (GQA / MQA): the grid b * h_k * ceil(sk / 128) is small and, under a causal mask, unbalanced (the first key block
+    // of a sequence sees every query tile, the last one a single tile).  With workspace from the caller the group's h / h_k query
+    // heads are dealt to n_split workgroups; each leaves fp32 partial sums and fa_bwd_sum_splits_kernel adds them in a fixed order.
+    const int head_k = vhead / p.n_split, split = vhead - head_k * p.n_split;
+    const int heads_here = p.h_ratio / p.n_split;            // query heads of this workgroup
 
     int sq = p.seqlen_q, sk = p.seqlen_k;
     int64_t q_row0 = 0, k_row0 = 0;
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     int qt_begin = 0;
     if (CAUSAL) qt_begin = max(0, n0 - delta) / kKvBlockM;
     const int tiles_per_head = max(0, n_q_tiles - qt_begin);
-    const int n_iters = tiles_per_head * p.h_ratio;
+    const int n_iters = tiles_per_head * heads_here;
 
     const int key_row = kb * 32 + l31;                   // this lane's key inside the 128-key block
     const int wave_k_lo = n0 + kb * 32, wave_k_hi = wave_k_lo + 31;
@@ -394,15 +436,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     // iteration -> (query head, first row of the q tile)
     auto tile_coords = [&](int it, int& hq, int& m0) {
         const int g = it / tiles_per_head;
-        hq = head_k * p.h_ratio + g;
+        hq = head_k * p.h_ratio + split * heads_here + g;
         m0 = (qt_begin + (it - g * tiles_per_head)) * kKvBlockM;
     };
-    // Q/dO tile `it` -> ring slot buf, and its 64 LSE / D values -> the stats slot, ALL by LDS-DMA: nothing returns to a VGPR, so
-    // hipcc has no reason to wait.  (Until round 2 the statistics went through a register on waves 0 / 1 under an exec-masked
-    // branch; hipcc answered with `s_waitcnt vmcnt(0)` at the top of every iteration - a write-after-write guard on that register
-    // for the paths that skipped the branch - i.e. right behind the DMA issue, exposing the full L2 / HBM latency of the NEXT
-    // tile in front of the MFMAs of the current one: 58 % of wave cycles parked, 35 % MFMA busy.)  LSE stays in natural-log units in
-    // LDS; the consumer scales it.
+    // Q/dO tile `it` -> ring slot buf by LDS-DMA issued from inline asm: nothing returns to a VGPR, hipcc has no reason to wait.
     auto issue_tile = [&](int it, int buf) {
         int hq, m0;
         tile_coords(it, hq, m0);
@@ -417,12 +454,27 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             dma16_to_lds_hidden(q_srd, q_src[i], lds0 + OFF_Q + buf * TILEB + piece * 1024);
             dma16_to_lds_hidden(do_srd, do_src[i], lds0 + OFF_DO + buf * TILEB + piece * 1024);
         }
-        if (wave < 2) {      // wave 0: LSE rows, wave 1: D rows (wave-uniform scalar branch); rows past the end arrive as 0
-            const int64_t so = ((int64_t)batch * p.h + hq) * p.lse_row_stride + m0;
-            const float* sb = uniform_ptr((wave == 0 ? p.lse_ptr : p.dsum_ptr) + so);
-            const srd_t st_srd = make_srd(sb, (uint32_t)rows * 4u);
-            dma4_to_lds_hidden(st_srd, (uint32_t)lane * 4u, lds0 + OFF_STAT + buf * STATB + wave * (kKvBlockM * 4));
-        }
+    };
+    // The 64 LSE / D values of a tile go through ONE register of waves 0 / 1: loaded when the tile's DMA is issued, transformed
+    // (-LSE*log2e, -D) and written to the stats slot at the END of the same iteration, in front of the vmcnt(0) that is there anyway.
+    // The consumers then need no per-element multiply / subtract: exp2(fma(s, c, nl)) and a dP chain that starts from -D (16 VALU
+    // fewer per wave-tile each).  The load is unconditional and its register is consumed on every path.  History: in round 1 the
+    // statistics went through a register under an exec-masked branch and hipcc answered with `s_waitcnt vmcnt(0)` at the top of
+    // every iteration - a write-after-write guard for the paths that skipped the branch - right behind the DMA issue, exposing the
+    // L2 / HBM latency of the NEXT tile in front of the MFMAs of the current one (58 % of wave cycles parked, 35 % MFMA busy);
+    // raw LSE / D by 4-byte LDS-DMA fixed that (16.6 -> 14.2 ms backward at C4), this form keeps the fix and drops the VALU.
+    const float st_mult = wave == 0 ? -kLog2e : -1.0f;
+    auto load_stat = [&](int it, bool valid) -> float {     // every wave, every iteration (an invalid request is a zero-record SRD: no access)
+        int hq, m0;
+        tile_coords(it, hq, m0);
+        const int rows = (valid && wave < 2) ? min(kKvBlockM, sq - m0) : 0;
+        const int64_t so = ((int64_t)batch * p.h + hq) * p.lse_row_stride + m0;
+        const float* sb = uniform_ptr((wave == 0 ? p.lse_ptr : p.dsum_ptr) + so);
+        const rsrc_t rs = make_rsrc(sb, (uint32_t)rows * 4u);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)lane * 4u, 0, 0));
+    };
+    auto store_stat = [&](float x, int buf) {
+        *(FA_LDS float*)(stat + buf * STATB + wave * (kKvBlockM * 4) + lane * 4) = x * st_mult;
     };
 
     // ---- prologue: this workgroup's K and V tiles + the first Q/dO tile ---------------------------
@@ -433,6 +485,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         dma16_to_lds_hidden(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
     }
     if (n_iters > 0) issue_tile(0, 0);
+    if (n_iters > 0 && wave < 2) store_stat(load_stat(0, true), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -445,6 +498,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         FA_LDS char* sbuf = stat + buf * STATB;
         const bool more = (it + 1 < n_iters);
         if (more) issue_tile(it + 1, buf ^ 1);             // ring slot buf^1 was last read in iteration it-1
+        const float st_next = load_stat(it + 1, more);
 
         // wave-level causal skip: all 32 rows of this wave's half are above the diagonal for all its 32 keys
         const int mh = m0 + 32 * qh;                       // first query row of this wave's half
@@ -461,10 +515,16 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             // key <= row + delta  <=>  8*g4 + e >= thr with everything tile- / lane-dependent folded into `thr` once per
             // tile (INT_MIN when this wave's tile needs no mask); the left side is a compile-time constant.
             const bool need_mask = CAUSAL && (wave_k_hi > mh + delta);
-            const int thr = need_mask ? (n0 + key_row) - (mh + 4 * hi + delta) : (int)0x80000000;
+            const int thr = (n0 + key_row) - (mh + 4 * hi + delta);
             f32x16 sacc, dpacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                        // the dP chain starts from -D (registers 4*g4.. = rows 32*qh + 8*g4 + 4*hi + {0..3})
+                const f32x4 nd4 = *(const FA_LDS f32x4*)(sbuf + kKvBlockM * 4 + (32 * qh + 8 * g4 + 4 * hi) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dpacc[4 * g4 + e] = nd4[e];
+            }
             // S and dP chains interleaved (consecutive MFMAs on different accumulators, see fa_bwd_dq_kernel)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -478,19 +538,16 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             f32x16 pacc;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                // registers 4*g4.. = query rows 32*qh + 8*g4 + 4*hi + {0..3} of the tile
-                const int rbase = 32 * qh + 8 * g4 + 4 * hi;
-                const f32x4 l4 = *(const FA_LDS f32x4*)(sbuf + rbase * 4);
-                const f32x4 d4 = *(const FA_LDS f32x4*)(sbuf + kKvBlockM * 4 + rbase * 4);
+                const f32x4 nl4 = *(const FA_LDS f32x4*)(sbuf + (32 * qh + 8 * g4 + 4 * hi) * 4);      // -LSE * log2(e) of the same rows
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g4 + e;
-                    float pv = fast_exp2(__builtin_fmaf(sacc[r], c, l4[e] * -kLog2e));
-                    if constexpr (CAUSAL) pv = (8 * g4 + e >= thr) ? pv : 0.f;
-                    pacc[r] = pv;
-                    sacc[r] = pv * (dpacc[r] - d4[e]);
-                }
+                for (int e = 0; e < 4; ++e) pacc[4 * g4 + e] = fast_exp2(__builtin_fmaf(sacc[4 * g4 + e], c, nl4[e]));
             }
+            if (need_mask) {                                        // wave-uniform branch: only diagonal tiles pay for the select
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pacc[r] = (8 * (r >> 2) + (r & 3) >= thr) ? pacc[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = pacc[r] * dpacc[r];     // dS = P * (dP - D) (flash_bwd_kernel.h:1354)
             // dV^T += dO^T P and dK^T += Q^T dS: 4*DB MFMAs whose A operands are transposed LDS reads.  The accumulators are inline-asm
             // operands, so hipcc has no latency model for these MFMAs and used to issue each read pair right in front of its
             // consumer (s_waitcnt lgkmcnt(0) before every MFMA: the LDS latency was exposed 4*DB times per tile).  The reads are
@@ -522,6 +579,8 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (more && wave < 2) store_stat(st_next, buf ^ 1);
+        asm volatile("" :: "v"(st_next));                   // consumed on every path: hipcc never has to guard the register at the loop top
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
         __syncthreads();
     }
@@ -574,8 +633,76 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         }
         __syncthreads();                                                       // scratch is reused by the next tensor
     };
-    reduce_and_store(dkacc, p.scale, dk_rs, dk_rowb);
-    reduce_and_store(dvacc, 1.0f, dv_rs, dv_rowb);
+    if (p.n_split == 1) {
+        reduce_and_store(dkacc, p.scale, dk_rs, dk_rowb);
+        reduce_and_store(dvacc, 1.0f, dv_rs, dv_rowb);
+        return;
+    }
+    // split group: the two q-halves still meet through LDS, the sum leaves as fp32 (unscaled) into this split's plane of the
+    // workspace; 16 bytes per lane per store, a key's row is 4 * D bytes
+    const int64_t plane = p.ws_rows * p.h_k * D;                                            // floats per (tensor, split)
+    const int64_t row0 = (p.cu_seqlens_k != nullptr ? k_row0 : (int64_t)batch * p.seqlen_k) + n0;
+    auto reduce_to_workspace = [&](f32x16 (&acc)[DB], int tensor) {
+        if (qh == 1) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(kb * XR + db * 16 + r) * 64 + lane] = acc[db][r];
+        }
+        __syncthreads();
+        if (qh == 0) {
+            float* base = uniform_ptr(p.ws + ((int64_t)tensor * p.n_split + split) * plane + (row0 * p.h_k + head_k) * D);
+            const rsrc_t rs = make_rsrc(base, (uint32_t)(keys_here - 1) * (uint32_t)(p.h_k * D * 4) + D * 4);
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    u32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        w[e] = __builtin_bit_cast(uint32_t, acc[db][4 * g4 + e] + xch[(kb * XR + db * 16 + 4 * g4 + e) * 64 + lane]);
+                    buf_store16(rs, (uint32_t)key_row * (uint32_t)(p.h_k * D * 4) + (32 * db + 8 * g4 + 4 * hi) * 4, w);   // rows >= keys_here fall outside the SRD
+                }
+        }
+        __syncthreads();                                                       // scratch is reused by the next tensor
+    };
+    reduce_to_workspace(dkacc, 0);
+    reduce_to_workspace(dvacc, 1);
+}
+
+// Sum of the n_split fp32 partial dK / dV planes (fixed order: deterministic), softmax scale on dK (flash_bwd_kernel.h:1652-1654),
+// rounding, strided store.  One thread = 8 consecutive d of one (key row, kv head); HBM-bound, 2 * n_split * 32 + 2 * 16 bytes each.
+constexpr int kSumThreads = 256;
+template <typename T, int D>
+__global__ __launch_bounds__(kSumThreads) void fa_bwd_sum_splits_kernel(const BwdKernelParams p) {
+    constexpr int CH = D / 8;                                                   // 16-byte output chunks per (row, head)
+    const int64_t n_items = p.ws_rows * p.h_k * CH;
+    const int64_t item = (int64_t)blockIdx.x * kSumThreads + threadIdx.x;
+    if (item >= n_items) return;
+    const int ch = (int)(item % CH);
+    const int64_t rh = item / CH;
+    const int hk = (int)(rh % p.h_k);
+    const int64_t row = rh / p.h_k;                                            // key row of the whole batch
+    const int64_t plane = p.ws_rows * p.h_k * D;
+    int64_t out_row = row, out_batch = 0;
+    if (p.cu_seqlens_k == nullptr) { out_batch = row / p.seqlen_k; out_row = row - out_batch * p.seqlen_k; }
+    else if (row >= p.cu_seqlens_k[p.b]) return;                               // padding rows of a packed tensor: no workgroup wrote them
+#pragma unroll
+    for (int tensor = 0; tensor < 2; ++tensor) {
+        const float* src = p.ws + (int64_t)tensor * p.n_split * plane + rh * D + ch * 8;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.n_split; ++s) {
+            a += *(const f32x4*)(src + (int64_t)s * plane);
+            b += *(const f32x4*)(src + (int64_t)s * plane + 4);
+        }
+        const float mult = tensor == 0 ? p.scale : 1.0f;
+        u32x4 w;
+        w.x = LP<T>::pack2(a[0] * mult, a[1] * mult); w.y = LP<T>::pack2(a[2] * mult, a[3] * mult);
+        w.z = LP<T>::pack2(b[0] * mult, b[1] * mult); w.w = LP<T>::pack2(b[2] * mult, b[3] * mult);
+        const TStride& st = tensor == 0 ? p.dk : p.dv;
+        T* dst = (T*)(tensor == 0 ? p.dk_ptr : p.dv_ptr) + out_batch * st.batch + out_row * st.row + (int64_t)hk * st.head + ch * 8;
+        *(u32x4*)dst = w;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -596,10 +723,14 @@ static hipError_t launch_dq_t(const BwdKernelParams& kp, hipStream_t s) {
 }
 template <typename T, int D>
 static hipError_t launch_dkdv_t(const BwdKernelParams& kp, hipStream_t s) {
-    const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h_k : kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k;
+    const uint32_t grid = (kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h_k : kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k) * (uint32_t)kp.n_split;
     if (grid == 0) return hipSuccess;
     if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
     else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || kp.n_split == 1) return e;
+    const int64_t items = kp.ws_rows * kp.h_k * (D / 8);
+    hipLaunchKernelGGL((fa_bwd_sum_splits_kernel<T, D>), dim3((uint32_t)((items + kSumThreads - 1) / kSumThreads)), dim3(kSumThreads), 0, s, kp);
     return hipGetLastError();
 }
 
@@ -617,9 +748,32 @@ hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
+#ifndef FA_KV_SPLIT_CAUSAL_PER_CU
+#define FA_KV_SPLIT_CAUSAL_PER_CU 4
+#endif
+// Split rule: double the split while the group divides evenly and the launch has fewer workgroups than 4 per CU (causal: the key
+// blocks of a sequence carry 1 .. n tiles of work, dynamic dispatch needs several workgroups per CU to even that out) or 1 per CU
+// (no mask: equal work, only an underfilled chip gains); packed tensors need total_k to size the planes.
+static int64_t dkdv_rows(const BwdKernelParams& kp) { return kp.cu_seqlens_k != nullptr ? kp.total_k : (int64_t)kp.b * kp.seqlen_k; }
+int64_t dkdv_workspace_bytes(const BwdKernelParams& kp, int32_t n_split) {
+    return n_split <= 1 ? 0 : 2 * (int64_t)n_split * dkdv_rows(kp) * kp.h_k * kp.d * 4;
+}
+int32_t dkdv_split(const BwdKernelParams& kp, int64_t avail_bytes) {
+    if (kp.h_ratio <= 1 || dkdv_rows(kp) <= 0) return 1;
+    const int64_t n_k_tiles = (kp.seqlen_k + kKvBlockN - 1) / kKvBlockN;
+    const int64_t wgs = (kp.cu_seqlens_k != nullptr ? (int64_t)varlen_slot_count(kp.total_k, kp.b, kKvBlockN, (uint32_t)n_k_tiles) : n_k_tiles * kp.b) * kp.h_k;
+    const int64_t want = kp.is_causal ? FA_KV_SPLIT_CAUSAL_PER_CU * 256 : 256;
+    int32_t split = 1;
+    while (split * 2 <= kp.h_ratio && kp.h_ratio % (split * 2) == 0 && wgs * split < want &&
+           (avail_bytes < 0 || dkdv_workspace_bytes(kp, split * 2) <= avail_bytes))
+        split *= 2;
+    return split;
+}
 hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_k_tiles = (uint32_t)((kp.seqlen_k + kKvBlockN - 1) / kKvBlockN);
     kp.varlen_slots = kp.cu_seqlens_k != nullptr ? varlen_slot_count(kp.total_k, kp.b, kKvBlockN, kp.n_k_tiles) : 0u;
+    kp.n_split = kp.ws != nullptr ? dkdv_split(kp, kp.ws_bytes) : 1;
+    kp.ws_rows = dkdv_rows(kp);
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

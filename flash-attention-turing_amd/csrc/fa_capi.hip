@@ -165,7 +165,21 @@ static int fill_bwd(const fa_bwd_params* p, fa::BwdKernelParams& kp) {
     if (p->cu_seqlens_q != nullptr) { kp.total_q = p->total_q; kp.total_k = p->total_k; }
     kp.scale = 1.0f / sqrtf((float)p->d);
     kp.scale_log2e = kp.scale * 1.4426950408889634f;
+    if (p->workspace_bytes < 0) return fail(FA_ERR_BAD_SHAPE, "workspace_bytes must be >= 0");
+    if (p->workspace != nullptr && p->workspace_bytes > 0) {
+        if ((reinterpret_cast<uintptr_t>(p->workspace) & 15u) != 0) return fail(FA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
+        kp.ws = (float*)p->workspace; kp.ws_bytes = p->workspace_bytes;
+    }
+    kp.n_split = 1;
     return FA_OK;
+}
+
+int64_t fa_bwd_workspace_bytes(const fa_bwd_params* p) {
+    fa::BwdKernelParams kp;
+    int rc = fill_bwd(p, kp);
+    if (rc) return rc;
+    if (p->b == 0 || p->seqlen_k == 0 || p->seqlen_q == 0) return 0;
+    return fa::dkdv_workspace_bytes(kp, fa::dkdv_split(kp, -1));
 }
 
 int fa_bwd_dot_do_o(const fa_bwd_params* p, void* stream) {

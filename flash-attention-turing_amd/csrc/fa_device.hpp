@@ -181,13 +181,6 @@ FA_DEV void dma16_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds
     }
 }
 
-// 4 bytes per lane: rsrc[voffset] -> lds_byte_addr + 4 * lane (256 B per wave instruction).  Used for per-row fp32 statistics.
-FA_DEV void dma4_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds_byte_addr) {
-    uint32_t keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd) : "memory");
-}
-
 FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }
 FA_DEV void lds_write16(FA_LDS char* base, uint32_t off, u32x4 v) { *(FA_LDS u32x4*)(base + off) = v; }
 FA_DEV void lds_write8(FA_LDS char* base, uint32_t off, u32x2 v) { *(FA_LDS u32x2*)(base + off) = v; }

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         const int rows_here = rows_of(t);
         const int ln = lane;
         const float l_tot = sum_both_halves(l_run);
-        const float inv = l_tot > 0.f ? fast_rcp(l_tot) : 0.f;
-        const float lse = l_tot > 0.f ? (m_run * c + fast_log2(l_tot)) * kLn2 : 0.f;
+        // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
+        const float inv = l_tot != 0.f ? fast_rcp(l_tot) : 0.f;
+        const float lse = l_tot != 0.f ? (m_run * c + fast_log2(l_tot)) * kLn2 : 0.f;
         if (hi == 0 && q_row < rows_here) lse_bh[t * kFwdBlockM + q_row] = lse;
 #pragma unroll
         for (int db = 0; db < DB; ++db)

@@ -53,7 +53,17 @@ struct BwdKernelParams {
     int64_t total_q, total_k;   // packed token counts (0 = unknown)
     float scale_log2e;
     float scale;
+    // dK/dV with the query-head group of a KV head split over n_split workgroups (fa_bwd.hip): fp32 partial sums
+    // ws[tensor 0 = dK, 1 = dV][split][key row of the whole batch][kv head][d]; n_split = 1: no workspace, direct output
+    float* ws;
+    int64_t ws_bytes;
+    int64_t ws_rows;            // key rows of the whole batch: b * seqlen_k, or total_k for packed tensors
+    int32_t n_split;
 };
+
+// query-head group split chosen for a dK/dV launch (1 = none) and the workspace it needs
+int32_t dkdv_split(const BwdKernelParams& kp, int64_t avail_bytes);
+int64_t dkdv_workspace_bytes(const BwdKernelParams& kp, int32_t n_split);
 
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);
 const char* fwd_kernel_name(int d);

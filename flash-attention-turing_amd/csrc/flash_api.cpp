@@ -146,6 +146,15 @@ std::vector<at::Tensor> mha_bwd(at::Tensor q, at::Tensor k, at::Tensor v, at::Te
     p.dtype = fa_dtype_of(q); p.is_causal = is_causal;
     p.q_stride = strides4(q); p.k_stride = strides4(k); p.v_stride = strides4(v); p.o_stride = strides4(out);
     p.do_stride = strides4(dout); p.dq_stride = strides4(dq); p.dk_stride = strides4(dk); p.dv_stride = strides4(dv);
+    // ABI 3: fp32 scratch that lets the dK/dV launch split a KV head's query-head group over several workgroups (GQA / MQA with few
+    // workgroups, causal imbalance); 0 bytes for MHA and for grids that fill the chip anyway
+    at::Tensor workspace;
+    const int64_t ws_bytes = fa_bwd_workspace_bytes(&p);
+    if (ws_bytes < 0) check_status((int)ws_bytes);
+    if (ws_bytes > 0) {
+        workspace = torch::empty({ws_bytes / 4}, q.options().dtype(torch::kFloat32));
+        p.workspace = workspace.data_ptr(); p.workspace_bytes = ws_bytes;
+    }
     check_status(fa_run_mha_bwd(&p, current_stream(q)));
     return {dq, dk, dv};
 }
@@ -233,6 +242,15 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     p.q_stride = strides3(q); p.k_stride = strides3(k); p.v_stride = strides3(v); p.o_stride = strides3(out);
     p.do_stride = strides3(dout); p.dq_stride = strides3(dq); p.dk_stride = strides3(dk); p.dv_stride = strides3(dv);
     p.total_q = q.size(0); p.total_k = k.size(0);
+    // ABI 3: fp32 scratch that lets the dK/dV launch split a KV head's query-head group over several workgroups (GQA / MQA with few
+    // workgroups, causal imbalance); 0 bytes for MHA and for grids that fill the chip anyway
+    at::Tensor workspace;
+    const int64_t ws_bytes = fa_bwd_workspace_bytes(&p);
+    if (ws_bytes < 0) check_status((int)ws_bytes);
+    if (ws_bytes > 0) {
+        workspace = torch::empty({ws_bytes / 4}, q.options().dtype(torch::kFloat32));
+        p.workspace = workspace.data_ptr(); p.workspace_bytes = ws_bytes;
+    }
     check_status(fa_run_mha_bwd(&p, current_stream(q)));
     return {dq, dk, dv};
 }

@@ -41,7 +41,8 @@ class BwdParams(ctypes.Structure):
                 ("dtype", _i32), ("is_causal", _i32),
                 ("q_stride", Strides), ("k_stride", Strides), ("v_stride", Strides), ("o_stride", Strides),
                 ("do_stride", Strides), ("dq_stride", Strides), ("dk_stride", Strides), ("dv_stride", Strides),
-                ("total_q", ctypes.c_int64), ("total_k", ctypes.c_int64)]
+                ("total_q", ctypes.c_int64), ("total_k", ctypes.c_int64),
+                ("workspace", _vp), ("workspace_bytes", ctypes.c_int64)]
 
 
 _lib = None
@@ -68,6 +69,8 @@ def lib():
         L.fa_bwd_dot_do_o.argtypes = [ctypes.POINTER(BwdParams), _vp]
         L.fa_bwd_dq.argtypes = [ctypes.POINTER(BwdParams), _vp]
         L.fa_bwd_dkdv.argtypes = [ctypes.POINTER(BwdParams), _vp]
+        L.fa_bwd_workspace_bytes.argtypes = [ctypes.POINTER(BwdParams)]
+        L.fa_bwd_workspace_bytes.restype = ctypes.c_int64
         L.fa_mha_fwd.argtypes = [_vp] * 5 + [_i32] * 8 + [_vp]
         L.fa_mha_bwd.argtypes = [_vp] * 10 + [_i32] * 8 + [_vp]
         L.fa_mha_varlen_fwd.argtypes = [_vp] * 7 + [_i32] * 8 + [_vp]
@@ -145,6 +148,27 @@ def bwd_params(q, k, v, o, lse, dout, dq, dk, dv, dsum, causal):
                     ("dq_stride", dq), ("dk_stride", dk), ("dv_stride", dv)):
         setattr(p, name, Strides(t.stride(0), t.stride(1), t.stride(2)))
     return p
+
+
+def bwd_workspace_bytes(params):
+    """bytes of fp32 scratch the dK/dV launch of these params would use to split a KV head's query-head group (0: no split)"""
+    n = lib().fa_bwd_workspace_bytes(ctypes.byref(params))
+    if n < 0:
+        check(int(n))
+    return int(n)
+
+
+def attach_workspace(params, like):
+    """allocate the scratch fa_bwd_workspace_bytes asks for (torch, on `like`'s device) and hang it on params; returns the tensor
+    (keep it alive until the launch has run) or None"""
+    import torch
+
+    n = bwd_workspace_bytes(params)
+    if n == 0:
+        return None
+    ws = torch.empty(n // 4, device=like.device, dtype=torch.float32)
+    params.workspace, params.workspace_bytes = ws.data_ptr(), n
+    return ws
 
 
 def bwd_stage(name, params, stream=None):

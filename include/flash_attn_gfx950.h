@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 2   /* 2: optional total_q / total_k appended to fa_fwd_params / fa_bwd_params */
+#define FA_ABI_VERSION 3   /* 2: optional total_q / total_k appended to fa_fwd_params / fa_bwd_params; 3: optional workspace appended to fa_bwd_params */
 
 enum fa_dtype { FA_FP16 = 0, FA_BF16 = 1 };
 
@@ -119,6 +119,14 @@ typedef struct fa_bwd_params {
     fa_strides q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
     int64_t total_q;            /* ABI 2, optional, see fa_fwd_params */
     int64_t total_k;
+    /* ABI 3, optional (NULL / 0 = none): fp32 scratch for the dK/dV kernel.  Its grid is b * h_k * ceil(seqlen_k / 128)
+     * workgroups; with few KV heads (GQA / MQA) that underfills the chip and, under a causal mask, is unbalanced (the first key
+     * block of a sequence meets every query tile, the last a single one).  Given this scratch, the h / h_k query heads of a KV
+     * head are dealt to several workgroups that leave fp32 partial sums here, and a second kernel adds them in a fixed order
+     * (results stay deterministic).  fa_bwd_workspace_bytes() is the size that lets the library choose freely; a smaller buffer
+     * limits the split, none keeps the single-pass behaviour of ABI 2.  Contents are unspecified afterwards. */
+    void* workspace;
+    int64_t workspace_bytes;
 } fa_bwd_params;
 
 /* ---- library info ---------------------------------------------------------------------- */
@@ -163,6 +171,9 @@ int fa_bwd_dot_do_o(const fa_bwd_params* params, void* stream);
  * exposed so that each kernel can be timed / profiled against its own roofline (bench.py `roofline_bwd`). */
 int fa_bwd_dq(const fa_bwd_params* params, void* stream);
 int fa_bwd_dkdv(const fa_bwd_params* params, void* stream);
+/* Bytes of fa_bwd_params.workspace the dK/dV launch of these params would use (0: it would not split; the `workspace` fields of
+ * the argument are ignored).  Host-only arithmetic.  Negative = error code. */
+int64_t fa_bwd_workspace_bytes(const fa_bwd_params* params);
 
 /* ---- measurement helpers ----------------------------------------------------------------- */
 /* Algorithmic FLOPs of one forward call (4*b*h*sq*sk*d, causal counts only visible pairs);

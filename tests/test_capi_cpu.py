@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/flash_attn_gfx950.h but not exported"
-    assert L.fa_abi_version() == 2
+    assert L.fa_abi_version() == 3
     assert b"gfx950" in L.fa_build_info()
 
 
@@ -64,6 +64,46 @@ def test_host_validation_error_codes_without_gpu():
 def test_struct_layout_matches_header():
     # 7 pointers + 8 int32 + 4 x 3 int64 + 2 int64 (ABI 2: total_q, total_k) ; 12 pointers + 8 int32 + 8 x 3 int64 + 2 int64
     assert ctypes.sizeof(capi.FwdParams) == 7 * 8 + 8 * 4 + 4 * 24 + 16
-    assert ctypes.sizeof(capi.BwdParams) == 12 * 8 + 8 * 4 + 8 * 24 + 16
+    # ABI 3: + workspace pointer + workspace_bytes at the end of the backward struct
+    assert ctypes.sizeof(capi.BwdParams) == 12 * 8 + 8 * 4 + 8 * 24 + 16 + 16
     # the ABI 1 prefix is unchanged: the appended fields sit at the very end
     assert capi.FwdParams.total_q.offset == 7 * 8 + 8 * 4 + 4 * 24 and capi.BwdParams.total_q.offset == 12 * 8 + 8 * 4 + 8 * 24
+    assert capi.BwdParams.workspace.offset == capi.BwdParams.total_k.offset + 8
+    assert capi.lib().fa_abi_version() == 3
+
+
+def _bwd_params_host_only(b, sq, sk, h, hk, d, causal, total_k=0, varlen=False):
+    """fa_bwd_params over dummy 16-byte aligned addresses: enough for the host-side arithmetic entry points (no launch)"""
+    buf = (ctypes.c_char * 64)()
+    addr = ctypes.addressof(buf)
+    addr += (-addr) % 16
+    p = capi.BwdParams()
+    for f in ("q", "k", "v", "o", "dout", "lse", "dq", "dk", "dv", "dsoftmax_sum"):
+        setattr(p, f, addr)
+    if varlen:
+        p.cu_seqlens_q = p.cu_seqlens_k = addr
+    p.b, p.seqlen_q, p.seqlen_k, p.h, p.h_k, p.d, p.dtype, p.is_causal = b, sq, sk, h, hk, d, 1, int(causal)
+    qs, ks = capi.Strides(sq * h * d, h * d, d), capi.Strides(sk * hk * d, hk * d, d)
+    p.q_stride = p.o_stride = p.do_stride = p.dq_stride = qs
+    p.k_stride = p.v_stride = p.dk_stride = p.dv_stride = ks
+    p.total_k = total_k
+    p._keep = buf
+    return p
+
+
+def test_dkdv_workspace_rule_host_arithmetic():
+    """fa_bwd_workspace_bytes: 0 for MHA and for grids that already fill the chip; planes of 2 x n_split x rows x h_k x d fp32 otherwise;
+    split doubles while the group divides evenly and the grid is below 4 workgroups per CU (causal) / 1 per CU (no mask)"""
+    W = lambda *a, **k: capi.bwd_workspace_bytes(_bwd_params_host_only(*a, **k))
+    plane = lambda b, sk, hk, d: 2 * b * sk * hk * d * 4
+    assert W(4, 8192, 8192, 32, 32, 128, True) == 0                              # MHA: never
+    assert W(4, 8192, 8192, 32, 1, 128, True) == 4 * plane(4, 8192, 1, 128)      # MQA causal 8k: 256 workgroups -> x4 = 1024
+    assert W(4, 8192, 8192, 32, 1, 128, False) == 0                              # same grid, no mask: one workgroup per CU already
+    assert W(1, 2048, 2048, 32, 1, 128, False) == 16 * plane(1, 2048, 1, 128)    # 16 workgroups -> x16 = 256
+    assert W(4, 4096, 4096, 32, 8, 128, True) == 0                               # GQA 32/8 at 4k: 1024 workgroups
+    assert W(2, 1024, 1024, 6, 1, 64, True) == 2 * plane(2, 1024, 1, 64)         # group of 6: 2 divides, 4 does not
+    assert W(2, 1024, 1024, 8, 1, 128, True, varlen=True) == 0                   # packed tensors without total_k: no split
+    assert W(2, 1024, 1024, 8, 1, 128, True, total_k=1500, varlen=True) == 8 * 2 * 1500 * 128 * 4
+    p = _bwd_params_host_only(1, 128, 128, 8, 1, 128, True)
+    p.workspace_bytes = -1
+    assert capi.lib().fa_bwd_workspace_bytes(ctypes.byref(p)) == capi.FA_ERR_BAD_SHAPE

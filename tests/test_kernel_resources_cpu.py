@@ -10,7 +10,7 @@ from _kernel_isa import analyse
 
 FILES = ["fa_fwd_pp.hip", "fa_bwd.hip"]
 # whole-kernel scratch that is known, outside every loop (prologue / epilogue), and bounded here so growth is noticed
-SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 64, "fa_bwd_dq_kernel": 64}
+SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 112, "fa_bwd_dq_kernel": 64}      # dK/dV: D = 64 causal carries 100 B since the second (workspace) epilogue
 # scratch ops INSIDE an MFMA loop: zero everywhere except the two D=64 backward kernels, which were deliberately squeezed to
 # 128 registers for two workgroups per CU (0.78-0.83x backward time measured WITH these few spill ops, see fa_bwd.hip and
 # profiles/r1_bwd_d64_occupancy_ab.log).  (kernel substring, head-dim substring) -> max ops per loop.  Accumulator shuffles: never.
@@ -32,7 +32,7 @@ def test_every_kernel_was_analysed(kernels):
     for (f, name), info in kernels.items():
         assert {"vgprs", "agprs", "scratch_bytes", "occupancy"} <= set(info), (f, name, info)
         # no vacuous passes: every MFMA kernel must have been seen WITH its MFMAs and at least one MFMA loop
-        if "dot_do_o" not in name:
+        if "dot_do_o" not in name and "sum_splits" not in name:      # the two HBM-bound helpers hold no MFMA
             assert info.get("mfma_total", 0) >= 16 and info.get("loops"), (f, name, info.get("mfma_total"), info.get("loops"))
 
 

@@ -28,6 +28,10 @@ CONFIGS = {
     "fp16 d64 8k causal": (4, 8192, 32, 32, 64, F16, True),
     "bf16 d128 8k mqa causal": (4, 8192, 32, 1, 128, BF16, True),
     "fp16 d128 gqa 4k causal": (4, 4096, 32, 8, 128, F16, True),
+    "bf16 d128 8k mha causal b1": (1, 8192, 32, 32, 128, BF16, True),
+    "bf16 d128 8k mqa causal b1": (1, 8192, 32, 1, 128, BF16, True),
+    "bf16 d128 8k gqa4 causal": (4, 8192, 32, 4, 128, BF16, True),
+    "bf16 d128 2k mqa": (1, 2048, 32, 1, 128, BF16, False),
 }
 
 
@@ -49,6 +53,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="")
     ap.add_argument("--stages", default="fwd,dq,dkdv")
+    ap.add_argument("--no-workspace", action="store_true", help="do not give ABI 3 builds the dK/dV scratch (single-pass dK/dV)")
     a = ap.parse_args()
     libs = {f"{chr(65 + i)}:{os.path.basename(p)[6:-3]}": load(p) for i, p in enumerate(a.libs)}
     stages = a.stages.split(",")
@@ -64,6 +69,20 @@ def main():
         lse, dsum = (torch.empty(b, h, s, device=dev, dtype=torch.float32) for _ in range(2))
         pf = capi.fwd_params(q, k, v, o, lse, causal)
         pb = capi.bwd_params(q, k, v, o, lse, do, dq, dk, dv, dsum, causal)
+        # ABI 3 builds get the dK/dV scratch they ask for (head-group split for GQA / MQA); older builds ignore the trailing fields
+        pbs, keep = {}, []
+        for n, L in libs.items():
+            pbs[n] = pb
+            if hasattr(L, "fa_bwd_workspace_bytes") and not a.no_workspace:
+                L.fa_bwd_workspace_bytes.restype = ctypes.c_int64
+                L.fa_bwd_workspace_bytes.argtypes = [ctypes.POINTER(capi.BwdParams)]
+                need = L.fa_bwd_workspace_bytes(ctypes.byref(pb))
+                if need > 0:
+                    pw = capi.bwd_params(q, k, v, o, lse, do, dq, dk, dv, dsum, causal)
+                    ws = torch.empty(need // 4, device=dev, dtype=torch.float32)
+                    pw.workspace, pw.workspace_bytes = ws.data_ptr(), need
+                    pbs[n] = pw
+                    keep.append(ws)
         st = torch.cuda.current_stream(dev).cuda_stream
         first = list(libs.values())[0]
         assert first.fa_run_mha_fwd(ctypes.byref(pf), st) == 0
@@ -79,8 +98,8 @@ def main():
                 if stage == "fwd":
                     return L.fa_run_mha_fwd(ctypes.byref(pf), st)
                 if stage == "bwd" or not hasattr(L, "fa_bwd_dq"):
-                    return L.fa_run_mha_bwd(ctypes.byref(pb), st)
-                return getattr(L, "fa_bwd_" + stage)(ctypes.byref(pb), st)
+                    return L.fa_run_mha_bwd(ctypes.byref(pbs[n]), st)
+                return getattr(L, "fa_bwd_" + stage)(ctypes.byref(pbs[n]), st)
             for n in libs:
                 assert run(n) == 0
                 torch.cuda.synchronize()
