@@ -507,6 +507,26 @@ def main():
                                     "roofline_bwd": bwd_rooflines(torch, capi, et, ec, eb, es, eh, ed)})
             del et
             torch.cuda.empty_cache()
+        # GQA / MQA backward under a causal mask (b4 s8192 h32 d128 bf16): few KV heads shrink and unbalance the dK/dV grid; with the
+        # ABI-3 workspace the launch splits a KV head's query-head group over workgroups.  Same FLOPs in every row.
+        gq = {}
+        for hk_ in (32, 8, 1):
+            et = make_inputs(torch, device, 4, 8192, 32, hk_, 128, "bf16", 555, True)
+            capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], True)
+            pb = capi.bwd_params(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"], et["dv"], et["dsum"], True)
+            g = lambda: capi.run_bwd(pb)
+            g(); sync()
+            single = event_time_ms(torch, g, 3, reps=3)
+            ws = capi.attach_workspace(pb, et["q"])
+            g(); sync()
+            split = event_time_ms(torch, g, 3, reps=3) if ws is not None else single
+            gq[f"h32_hk{hk_}"] = {"bwd_ms": split, "bwd_ms_without_workspace": single, "workspace_bytes": 0 if ws is None else ws.numel() * 4,
+                                  "bwd_tflops": 2.5 * fwd_flops(4, 8192, 8192, 32, 128, True) / split / 1e9}
+            del et, pb, ws
+            torch.cuda.empty_cache()
+        for v_ in gq.values():
+            v_["vs_mha"] = v_["bwd_ms"] / gq["h32_hk32"]["bwd_ms"]
+        extra["gqa_bwd_b4_s8192_d128_bf16_causal"] = gq
         # seqlen sweep of the reference's published chart (README.md:7-16): b4 h32 d128
         for cz in (False, True):
             sweep = {}

@@ -303,11 +303,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                     }
             }
         }
-#if defined(FA_X_OPTMASK)
+        // (masked tiles too, except tile 0, which meets an empty running max: its pass would always be thrown away)
         if (kOptimistic && (!decltype(masked)::value || u > 0)) {
-#else
-        if constexpr (kOptimistic && !decltype(masked)::value) {
-#endif
             // Optimistic pass: exponentials against the running max as it stands, no row-max reduction.  A lane whose 32 terms sum to
             // <= 2^kPpDeferLog2 holds no term above that bound (the same bound the deferred-max rule below guarantees), so P, l and O
             // stay in range and the pass stands; otherwise (Inf and NaN included) the wave falls through to the exact path, which

@@ -171,6 +171,14 @@ def attach_workspace(params, like):
     return ws
 
 
+def run_bwd(params, stream=None):
+    """the whole backward (dot_do_o, dQ, dK/dV) from a parameter struct, e.g. one with a workspace attached"""
+    import torch
+
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    check(lib().fa_run_mha_bwd(ctypes.byref(params), s))
+
+
 def bwd_stage(name, params, stream=None):
     """run one backward launch: name in {'dot_do_o', 'dq', 'dkdv'}"""
     import torch
