@@ -42,6 +42,13 @@ constexpr float kPpDeferLog2 = 6.0f;
 // spill and no extra instruction in any loop; interleaved A/B, causal forward (profiles/r1_fwd_d64_occupancy_ab.log):
 // 0.90-0.93x time at 8k, 0.96x at 16k, 0.75x at 2k, 0.71x at 512; non-causal and D = 128 unchanged; outputs bit-identical.
 #define FA_PP_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+// Matrix phase = NPV P*V steps, then NQK QK^T steps.  P*V step j -> (output block db = j % DB, key sub-tile ts = j / DB): consecutive
+// MFMAs go to different accumulators (per accumulator the ts order, hence the result, is unchanged; 0.3-0.5 % over db-major at D = 128;
+// alternating P*V and QK^T steps measured the same, profiles/r2_fwd_step_order_ab.log).
+#define FA_STEP_IS_PV(j) ((j) < NPV)
+#define FA_STEP_IDX(j) ((j) < NPV ? (j) : (j) - NPV)
+#define FA_PV_DB(j) ((j) % DB)
+#define FA_PV_TS(j) ((j) / DB)
 #ifndef FA_PP_OPTIMISTIC
 #define FA_PP_OPTIMISTIC(D, CAUSAL) ((D) == 128 || !(CAUSAL))      // D = 64 causal: the extra path does not fit its 128 registers
 #endif
@@ -224,14 +231,14 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     constexpr bool kOptimistic = FA_PP_OPTIMISTIC(D, CAUSAL);
     constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? 2 : 4;      // fragments in flight; D = 64 has 128 VGPRs only
     auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
-        if (j < NPV) {
-            const int db = j / 4, ts = j % 4;
+        if (FA_STEP_IS_PV(j)) {
+            const int pj = FA_STEP_IDX(j), db = FA_PV_DB(pj), ts = FA_PV_TS(pj);
             FA_LDS char* vbuf = vring + slot_v * TILEB;
             const u32x2 a0 = lds_read_tr8(vbuf, v_rd[0][db] + ts * 16 * ROWB);
             const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
             return u32x4{a0.x, a0.y, a1.x, a1.y};
         }
-        const int i = j - NPV, ks = i / 2, bi = i % 2;
+        const int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
         return lds_read16(kring + slot_k * TILEB, k_rd[ks] + bi * 32 * ROWB);
     };
     // read bases with the ring origin folded in and hidden from the compiler: with compile-time ring slots every fragment read is
@@ -244,13 +251,13 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 #pragma unroll
         for (int db = 0; db < DB; ++db) { v_abs[sec][db] = lds_addr(vring) + v_rd[sec][db]; asm volatile("" : "+v"(v_abs[sec][db])); }
     auto m_frag_c = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
-        if (j < NPV) {
-            const int db = j / 4, ts = j % 4;
+        if (FA_STEP_IS_PV(j)) {
+            const int pj = FA_STEP_IDX(j), db = FA_PV_DB(pj), ts = FA_PV_TS(pj);
             const u32x2 a0 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_abs[0][db], slot_v * TILEB + ts * 16 * ROWB);
             const u32x2 a1 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_abs[1][db], slot_v * TILEB + ts * 16 * ROWB);
             return u32x4{a0.x, a0.y, a1.x, a1.y};
         }
-        const int i = j - NPV, ks = i / 2, bi = i % 2;
+        const int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
         return lds_read16((const FA_LDS char*)(uintptr_t)k_abs[ks], slot_k * TILEB + bi * 32 * ROWB);
     };
     u32x4 pre[PF];
@@ -265,10 +272,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             constexpr int j = decltype(jc)::value;
             if constexpr (j + PF < NST) fr[j + PF] = m_frag(j + PF, ring_um1, ring_u);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j < NPV) {
-                oacc[j / 4] = LP<T>::mfma(fr[j], pf[j % 4], oacc[j / 4]);
+            if constexpr (FA_STEP_IS_PV(j)) {
+                constexpr int pj = FA_STEP_IDX(j);
+                oacc[FA_PV_DB(pj)] = LP<T>::mfma(fr[j], pf[FA_PV_TS(pj)], oacc[FA_PV_DB(pj)]);
             } else {
-                constexpr int i = j - NPV, ks = i / 2, bi = i % 2;
+                constexpr int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
                 if constexpr (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
@@ -430,10 +438,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                     constexpr int j = decltype(jc)::value;
                     if constexpr (j + PF < NST) fr[j + PF] = m_frag_c(j + PF, S_UM1, S_U);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (j < NPV) {
-                        oacc[j / 4] = LP<T>::mfma(fr[j], pf[j % 4], oacc[j / 4]);
+                    if constexpr (FA_STEP_IS_PV(j)) {
+                        constexpr int pj = FA_STEP_IDX(j);
+                        oacc[FA_PV_DB(pj)] = LP<T>::mfma(fr[j], pf[FA_PV_TS(pj)], oacc[FA_PV_DB(pj)]);
                     } else {
-                        constexpr int i = j - NPV, ks = i / 2, bi = i % 2;
+                        constexpr int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
                         if constexpr (ks == 0) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
