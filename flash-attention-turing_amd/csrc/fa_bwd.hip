@@ -90,6 +90,15 @@ template <typename T, int D, bool CAUSAL>
 #ifndef FA_DQ_NO_UNROLL
 #define FA_DQ_NO_UNROLL 0
 #endif
+// dK/dV: k-steps whose K / V fragments are held in registers (D = 128: all 8 of K, 2 of V - the most that fits the 128 VGPRs next to
+// the 128 accumulator registers without a spill; all 8 of V spills and runs 1.4-1.8x slower; D = 64 runs on 64 + 64 registers: none).
+// Timing-only ablation first (profiles/r2_bwd_dkdv_lds_ab.log): no K / V fragment reads at all = -14..-18 % of the kernel.
+#ifndef FA_KV_KREG
+#define FA_KV_KREG(D) ((D) == 128 ? 8 : 0)
+#endif
+#ifndef FA_KV_VREG
+#define FA_KV_VREG(D) ((D) == 128 ? 2 : 0)
+#endif
 #define FA_KV_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
 __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
@@ -236,7 +245,9 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
                 f32x16 sacc, dpacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = kDpFromMinusD ? negd[r] : 0.f; }   // dP chain from -D: dP - D comes out of the MFMAs
-                // S^T and dP^T chains interleaved: consecutive MFMAs never share an accumulator; per-chain order unchanged
+                // S^T and dP^T chains interleaved: consecutive MFMAs never share an accumulator; per-chain order unchanged.  (hipcc waits
+                // for every pair of fragment reads right behind its issue here; requesting them 2-6 steps ahead by hand changed
+                // nothing - the partner wave on the SIMD covers it - profiles/r2_bwd_dkdv_lds_ab.log.)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const u32x4 kf = lds_read16(kbuf, row_rd[ks] + bi * 32 * ROWB);
@@ -489,6 +500,16 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // This wave's K (and V) fragments of the first KREG (VREG) k-steps stay in registers for the whole loop: they never change, and the
+    // kernel is LDS-bandwidth-bound - every S / dP MFMA used to read BOTH its operands from LDS, 384 KiB per workgroup-tile against
+    // 2048 MFMA cycles per SIMD.  -5 % (C4) to -13 % (8k causal), bit-identical.
+    constexpr int KREG = FA_KV_KREG(D) < KS ? FA_KV_KREG(D) : KS, VREG = FA_KV_VREG(D) < KS ? FA_KV_VREG(D) : KS;
+    u32x4 kreg[KREG > 0 ? KREG : 1], vreg[VREG > 0 ? VREG : 1];
+#pragma unroll
+    for (int ks = 0; ks < KREG; ++ks) kreg[ks] = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
+#pragma unroll
+    for (int ks = 0; ks < VREG; ++ks) vreg[ks] = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
+
     for (int it = 0; it < n_iters; ++it) {
         int hq, m0;
         tile_coords(it, hq, m0);
@@ -525,13 +546,16 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dpacc[4 * g4 + e] = nd4[e];
             }
-            // S and dP chains interleaved (consecutive MFMAs on different accumulators, see fa_bwd_dq_kernel)
+            // S and dP chains interleaved (consecutive MFMAs on different accumulators, see fa_bwd_dq_kernel).  hipcc leaves these reads
+            // one MFMA of look-ahead (`ds_read x2; s_waitcnt lgkmcnt(2); v_mfma`); requesting them further ahead by hand, as the dQ
+            // kernel does, costs address-register spills here at every depth tried (1-4 steps: 10-26 scratch loads per tile, each
+            // followed by vmcnt(0)): the kernel has 128 VGPRs next to its 128 accumulator registers and they are all spoken for.
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 qa = lds_read16(qbuf, row_rd[ks] + qh * 32 * ROWB);
-                const u32x4 kf = lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
+                const u32x4 kf = ks < KREG ? kreg[ks < KREG ? ks : 0] : lds_read16(ktile, row_rd[ks] + kb * 32 * ROWB);
                 const u32x4 da = lds_read16(dobuf, row_rd[ks] + qh * 32 * ROWB);
-                const u32x4 vf = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
+                const u32x4 vf = ks < VREG ? vreg[ks < VREG ? ks : 0] : lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
                 sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
                 dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
             }
