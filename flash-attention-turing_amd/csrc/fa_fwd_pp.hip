@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // profiles/r2_fwd_phase_timing.log): the period of the ping-pong is the SUM of the two groups' matrix phases (the softmax
     // phases hide behind them), and a matrix phase took 1270 cycles for 1024 cycles of MFMA issue.
     constexpr bool kOptimistic = FA_PP_OPTIMISTIC(D, CAUSAL);
-    constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? 2 : 4;      // fragments in flight; D = 64 has 128 VGPRs only
+    constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? 2 : 4;      // fragments in flight (3 / 6 / 8 measured within 0.5 % of 4); D = 64 has 128 VGPRs only
     auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
         if (FA_STEP_IS_PV(j)) {
             const int pj = FA_STEP_IDX(j), db = FA_PV_DB(pj), ts = FA_PV_TS(pj);
