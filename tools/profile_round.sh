@@ -11,6 +11,9 @@ export TMPDIR=/tmp
 mkdir -p "$OUT"; cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extra > "$OUT/bench_stdout.json" 2> "$OUT/bench_stderr.log"
 echo "bench stats rc=$?"
+# the same for BASELINE configs[3] (forward + backward, b4 s8192 bf16): per-kernel averages of dot_do_o, dQ, dK/dV next to the forward
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_c4_stats" -- python "$R/bench.py" --workload c4 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > "$OUT/bench_c4_stdout.json" 2> "$OUT/bench_c4_stderr.log"
+echo "bench c4 stats rc=$?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/fwd_c3_$ctr" -- python "$R/tools/run_fwd_once.py" --seq 16384 --causal 1 --iters 4 > "$OUT/fwd_c3_$ctr.stdout" 2>&1
   echo "fwd c3 $ctr rc=$?"

@@ -12,6 +12,8 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flash-attention-turing_amd"))
+from flash_attn_turing import capi  # noqa: E402
 LIB = os.path.join(ROOT, "flash-attention-turing_amd", "csrc", "libflash_attn_gfx950.so")
 vp, i32 = ctypes.c_void_p, ctypes.c_int
 
@@ -75,8 +77,10 @@ def main():
                 code = 0 if dt == F16 else 1
                 if mode == "dense":
                     fwd = lambda: L.fa_mha_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), b, sq, sk, h, hk, d, code, int(causal), st)
-                    bwd = lambda: L.fa_mha_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                               dv.data_ptr(), dsum.data_ptr(), b, sq, sk, h, hk, d, code, int(causal), st)
+                    # parameter-struct entry point so that GQA / MQA shapes get the dK/dV workspace (head-group split, C ABI 3)
+                    pb = capi.bwd_params(q, k, v, o, lse, do, dq, dk, dv, dsum, causal)
+                    ws = capi.attach_workspace(pb, q)      # noqa: F841  (kept alive by the closure below)
+                    bwd = lambda pb=pb, ws=ws: capi.lib().fa_run_mha_bwd(ctypes.byref(pb), st)
                 else:   # same data seen as a packed batch of b equal-length sequences
                     cq = torch.arange(0, (b + 1) * sq, sq, device=dev, dtype=torch.int32)
                     ck = torch.arange(0, (b + 1) * sk, sk, device=dev, dtype=torch.int32)
