@@ -18,6 +18,10 @@
 //     wave; only diagonal / tail tiles take the element mask.
 //   * O is normalised, rounded to fp16/bf16, staged through LDS and stored as whole rows.
 //   * two wave groups (waves 0-3 / 4-7) run the matrix phase of one against the softmax phase of the other.
+//   * steady state: the running max is only refreshed when a row outgrows it by 2^6, and the softmax first runs an optimistic
+//     pass WITHOUT the row-max reduction (exact path only if a lane's partial row sum exceeds 2^6); the matrix phase is one
+//     hand-pipelined stream of MFMAs with LDS fragments requested 4 steps ahead; at D = 128 the loop runs three tiles per trip
+//     so that ring slots are compile-time constants (no address arithmetic left in it).
 //
 // Semantics follow SURVEY.md Appendix A; dead rows produce O = 0 and LSE = 0.0
 // (flash_fwd_kernel.h:720-728,767-771) without relying on a zero pre-fill of the outputs.
