@@ -605,6 +605,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         }
         if (more && wave < 2) store_stat(st_next, buf ^ 1);
         asm volatile("" :: "v"(st_next));                   // consumed on every path: hipcc never has to guard the register at the loop top
+        // (timing-only ablations, profiles/r2_bwd_dkdv_lds_ab.log: without this wait -0.2 %, without wait AND barrier -5..-6 %)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
         __syncthreads();
     }
