@@ -245,8 +245,8 @@ def test_large_magnitude_inputs_stay_finite(gpu):
 
 def test_launch_path_is_hip_graph_capturable(gpu):
     """The C ABI promises no allocation, no synchronisation and no host-dependent state at launch (include/flash_attn_gfx950.h), so
-    forward + backward must be capturable in a HIP graph and replay to the same bits - dense and varlen (compact grid: the slot lookup
-    reads cu_seqlens on the device, nothing on the host)."""
+    forward + backward must be capturable in a HIP graph and replay to the same bits - dense (single-pass dK/dV) and varlen (compact grid:
+    the slot lookup reads cu_seqlens on the device, nothing on the host; with a caller-provided workspace, i.e. the split dK/dV + sum kernel)."""
     import ctypes
 
     from flash_attn_turing import capi
@@ -280,6 +280,9 @@ def test_launch_path_is_hip_graph_capturable(gpu):
     fp = capi.FwdParams(**common)
     bp = capi.BwdParams(dout=dov.data_ptr(), dq=dqv.data_ptr(), dk=dkv.data_ptr(), dv=dvv.data_ptr(), dsoftmax_sum=dsv.data_ptr(),
                         do_stride=row(dov), dq_stride=row(dqv), dk_stride=row(dkv), dv_stride=row(dvv), **common)
+
+    ws = capi.attach_workspace(bp, qv)            # ABI 3: GQA 4/2 on a small grid -> the dK/dV launch splits the head group (dK/dV + sum kernel)
+    assert ws is not None and bp.workspace_bytes > 0
 
     def varlen(stream):
         capi.check(L.fa_run_mha_fwd(ctypes.byref(fp), stream))
