@@ -44,3 +44,24 @@ for causal in (False, True):
     y = np.array([u for _, _, u, _, _ in r])
     b, a = np.polyfit(x, y, 1)
     print(f"causal={causal}: fit  t = {a:.1f} us + {b:.2f} us per tile-iteration  (steady state at 8k: ~1.7 us per tile-iteration)")
+
+# launch-to-launch floor on an in-order stream: one-workgroup forward (b1 s64 h1: a single 64-key tile) and a 1-element torch kernel
+def per_launch(f, n=200):
+    for _ in range(20):
+        f()
+    ts = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) / n * 1e3)
+    return float(np.median(ts))
+
+
+q1, k1, v1 = (torch.randn(1, 64, 1, 128, device=dev, dtype=torch.float16) for _ in range(3))
+o1, l1 = torch.empty_like(q1), torch.empty(1, 1, 64, device=dev, dtype=torch.float32)
+x = torch.zeros(1, device=dev)
+print(f"one-workgroup forward (1 key tile): {per_launch(lambda: capi.mha_fwd(q1, k1, v1, o1, l1, False)):.2f} us per launch;  1-element torch add_: {per_launch(lambda: x.add_(1.0)):.2f} us per launch")
