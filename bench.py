@@ -378,7 +378,8 @@ def bwd_rooflines(torch, capi, et, causal, b, s, h, d):
             byts = 2.0 * b * s * h * d * 2 + b * h * s * 4.0           # read O and dO once, write D
             gbps = byts / ms / 1e6
             out[name] = {"kernel": kern, "bound": "hbm", "avg_launch_ms": ms, "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": byts}
+                         "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": byts,
+                         "note": "stand-alone entry point; fa_run_mha_bwd (what bwd_ms times) computes D inside the dQ kernel and does not launch it"}
         else:
             tf = flop_mult * pair * d / ms / 1e9
             out[name] = {"kernel": kern, "bound": "mfma", "avg_launch_ms": ms, "achieved": tf, "peak": PEAK_DENSE_FP16_TFLOPS,

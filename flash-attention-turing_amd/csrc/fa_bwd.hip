@@ -132,6 +132,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
 
     const T* q_base = uniform_ptr((const T*)p.q_ptr + q_boff + (q_row0 + m0) * p.q.row + (int64_t)head * p.q.head);
     const T* do_base = uniform_ptr((const T*)p.do_ptr + do_boff + (q_row0 + m0) * p.dout.row + (int64_t)head * p.dout.head);
+    const T* o_base = uniform_ptr((const T*)p.o_ptr + (p.cu_seqlens_q != nullptr ? 0 : (int64_t)batch * p.o.batch) + (q_row0 + m0) * p.o.row + (int64_t)head * p.o.head);
     T* dq_base = uniform_ptr((T*)p.dq_ptr + dq_boff + (q_row0 + m0) * p.dq.row + (int64_t)head * p.dq.head);
     const T* k_base = uniform_ptr((const T*)p.k_ptr + k_boff + k_row0 * p.k.row + (int64_t)head_k * p.k.head);
     const T* v_base = uniform_ptr((const T*)p.v_ptr + v_boff + k_row0 * p.v.row + (int64_t)head_k * p.v.head);
@@ -142,6 +143,8 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
     const rsrc_t q_rs = make_rsrc(q_base, (uint32_t)(rows_here - 1) * q_rowb + ROWB);
     const rsrc_t do_rs = make_rsrc(do_base, (uint32_t)(rows_here - 1) * do_rowb + ROWB);
     const rsrc_t dq_rs = make_rsrc(dq_base, (uint32_t)(rows_here - 1) * dq_rowb + ROWB);
+    const uint32_t o_rowb = (uint32_t)(p.o.row * 2);
+    const rsrc_t o_rs = make_rsrc(o_base, (uint32_t)(rows_here - 1) * o_rowb + ROWB);
     const srd_t k_srd = make_srd(k_base, sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
     const srd_t v_srd = make_srd(v_base, sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
 
@@ -194,10 +197,27 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
         qf[ks] = buf_load16(q_rs, (uint32_t)q_row * q_rowb + (2 * ks + hi) * 16);
         dof[ks] = buf_load16(do_rs, (uint32_t)q_row * do_rowb + (2 * ks + hi) * 16);
     }
+    // D_i = rowsum(dO_i * O_i) (flash_bwd_preprocess_kernel.h:23-96) is computed HERE, from the dO fragments this lane holds anyway and the
+    // matching O fragments (one extra 64 KiB read per workgroup, hidden behind the first K / V tiles), and written to the workspace for
+    // the dK/dV launch that follows on the stream: the separate fa_bwd_dot_do_o launch (0.09 ms at C4, ~6 % of a 512-long backward) is
+    // no longer on the path of fa_run_mha_bwd.  fp32 products and sums, like the stand-alone kernel.
     float lse2 = 0.f, dsum = 0.f;   // rows past the end keep 0 (they contribute nothing: Q = dO = 0)
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 of = buf_load16(o_rs, (uint32_t)q_row * o_rowb + (2 * ks + hi) * 16);      // rows past the end read zeros
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                part += LP<T>::to_float((uint16_t)(of[w] & 0xffff)) * LP<T>::to_float((uint16_t)(dof[ks][w] & 0xffff));
+                part += LP<T>::to_float((uint16_t)(of[w] >> 16)) * LP<T>::to_float((uint16_t)(dof[ks][w] >> 16));
+            }
+        }
+        dsum = sum_both_halves(part);           // a lane holds the even (hi = 0) or odd (hi = 1) 16-byte slots of its row
+    }
     if (q_row < rows_here) {
         lse2 = p.lse_ptr[stat_off + q_row] * kLog2e;
-        dsum = p.dsum_ptr[stat_off + q_row];
+        if (hi == 0) p.dsum_ptr[stat_off + q_row] = dsum;
     }
     const float c = p.scale_log2e;
     // D = 128: a loop-invariant block of -D_i feeds the first dP MFMA as its C operand, so dP - D costs no VALU (16 registers; the

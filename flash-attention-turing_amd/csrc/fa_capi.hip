@@ -212,10 +212,10 @@ int fa_run_mha_bwd(const fa_bwd_params* p, void* stream) {
     if (rc) return rc;
     if (p->b == 0) return FA_OK;
     hipStream_t s = (hipStream_t)stream;
-    // Same three-step structure as the reference's run_flash_bwd (flash_bwd_launch_template.h:69-146),
-    // same stream, no host sync in between.
+    // The reference's run_flash_bwd launches dot_do_o, dQ, dK/dV (flash_bwd_launch_template.h:69-146).  Here the dQ kernel computes
+    // D = rowsum(dO * O) for its own rows in its prologue and leaves it in dsoftmax_sum for the dK/dV launch: two launches, same
+    // stream, no host sync in between.  (fa_bwd_dot_do_o stays available as a stand-alone entry point.)
     if (p->seqlen_q > 0) {
-        if ((rc = hip_status(fa::launch_bwd_dot_do_o(kp, p->dtype, s), "fa_bwd_dot_do_o launch"))) return rc;
         if ((rc = hip_status(fa::launch_bwd_dq(kp, p->dtype, s), "fa_bwd_dq launch"))) return rc;
     }
     if (p->seqlen_k > 0) {

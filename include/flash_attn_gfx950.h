@@ -163,12 +163,14 @@ int fa_mha_varlen_bwd(const void* q, const void* k, const void* v, const void* o
                       int32_t h, int32_t h_k, int32_t d,
                       int32_t dtype, int32_t is_causal, void* stream);
 
-/* D = rowsum(dO * O) alone (replaces flash_bwd_dot_do_o_kernel, flash_bwd_preprocess_kernel.h:23-96);
- * exposed because it is the one HBM-bound kernel on the path and is measured separately. */
+/* D = rowsum(dO * O) alone (replaces flash_bwd_dot_do_o_kernel, flash_bwd_preprocess_kernel.h:23-96): the one HBM-bound kernel of
+ * the reference's path.  Since round 2 fa_run_mha_bwd no longer launches it (the dQ kernel computes D in its prologue); it stays as a
+ * stand-alone entry point and is measured separately. */
 int fa_bwd_dot_do_o(const fa_bwd_params* params, void* stream);
-/* The other two launches of run_flash_bwd, individually (flash_bwd_launch_template.h:95-146): dQ and dK/dV.  Both read
- * params->dsoftmax_sum, i.e. fa_bwd_dot_do_o must have run on the same stream before.  fa_run_mha_bwd == the three in order;
- * exposed so that each kernel can be timed / profiled against its own roofline (bench.py `roofline_bwd`). */
+/* The other two launches of run_flash_bwd, individually (flash_bwd_launch_template.h:95-146): dQ and dK/dV.  fa_bwd_dq computes D for
+ * its rows itself (from O and dO) and WRITES params->dsoftmax_sum; fa_bwd_dkdv READS it, i.e. fa_bwd_dq (or fa_bwd_dot_do_o) must
+ * have run on the same stream before.  fa_run_mha_bwd == fa_bwd_dq then fa_bwd_dkdv; exposed so that each kernel can be timed /
+ * profiled against its own roofline (bench.py `roofline_bwd`). */
 int fa_bwd_dq(const fa_bwd_params* params, void* stream);
 int fa_bwd_dkdv(const fa_bwd_params* params, void* stream);
 /* Bytes of fa_bwd_params.workspace the dK/dV launch of these params would use (0: it would not split; the `workspace` fields of
