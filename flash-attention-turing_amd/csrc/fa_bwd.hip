@@ -1,11 +1,15 @@
 // fa_bwd.hip — fused attention backward for MI355X (gfx950, CDNA4).
 //
-// Three kernels on one stream, mirroring the reference's run_flash_bwd
-// (csrc/flash_attn/src/flash_bwd_launch_template.h:69-146) but re-designed for wave64 / MFMA:
+// The kernels of the reference's run_flash_bwd (csrc/flash_attn/src/flash_bwd_launch_template.h:69-146), re-designed for
+// wave64 / MFMA:
 //
 //   fa_bwd_dot_do_o_kernel  D[b,h,i] = sum_d dO*O                 (flash_bwd_preprocess_kernel.h:23-96)
 //   fa_bwd_dq_kernel        dQ = scale * sum_j dS_ij K_j           (flash_bwd_kernel.h:28-825)
 //   fa_bwd_dkdv_kernel      dV = sum_i P_ij^T dO_i, dK = scale * sum_i dS_ij^T Q_i   (:842-1676)
+//   fa_bwd_sum_splits_kernel  adds the fp32 partial dK / dV planes when the dK/dV launch split a GQA head group (C ABI 3)
+//
+// A backward call is TWO launches on one stream, dQ then dK/dV (plus the plane sum when split): the dQ kernel computes D for
+// its own rows in its prologue and leaves it in the workspace for dK/dV; the stand-alone dot_do_o kernel stays as an entry point.
 //
 // Like the reference this is the deterministic, atomics-free 7-GEMM form (S and dP are
 // recomputed in both kernels).  Differences that matter on CDNA4:
@@ -15,7 +19,9 @@
 //     MFMAs straight from registers, Q^T / dO^T operands come from hardware transposing LDS reads,
 //     the dK^T / dV^T accumulators live in AGPRs;
 //   * the GQA group loop is fused into the dK/dV kernel (the reference materialises per-q-head
-//     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312).
+//     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312); with caller-provided fp32 scratch the group is
+//     split over workgroups when the grid would otherwise be small or causally unbalanced;
+//   * operands that never change inside a kernel's loop live in registers (Q / dO fragments in dQ, K and part of V in dK/dV).
 #include <type_traits>
 #include "fa_device.hpp"
 #include "fa_params.hpp"
