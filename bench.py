@@ -246,6 +246,93 @@ def event_time_ms(torch, fn, iters, reps=1):
     return statistics.median(means)
 
 
+def launch_time_distribution(torch, fn, n):
+    """n individually timed launches (one HIP-event pair each, on the launch stream): mean / median / min / max in ms.
+    SURVEY.md 8(d) asks for median AND min over >= 30 iterations; the mean of back-to-back launches (event_time_ms) stays the figure
+    `achieved` is computed from, because that is what a rocprofv3 --stats average of the same command reproduces."""
+    import statistics
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    evs[-1][1].synchronize()
+    ts = [a.elapsed_time(b) for a, b in evs]
+    return {"n": n, "mean_ms": sum(ts) / n, "median_ms": statistics.median(ts), "min_ms": min(ts), "max_ms": max(ts)}
+
+
+class PowerSampler:
+    """Polls the GPU's own sensors (amdgpu sysfs: hwmon power1_average / power1_input in microwatts, freq1_input = sclk in Hz) from a
+    host thread while a region runs.  Substantiates (or refutes) the "power-limited under MFMA load" reading of the clock
+    counters.  Costs a few file reads per 5 ms on one host core; nothing is launched on the GPU."""
+
+    def __init__(self, device_index=0, period_s=0.005):
+        import glob
+        import threading
+
+        self.period, self.samples, self._stop, self._thr = period_s, [], threading.Event(), None
+        self.power_path = self.sclk_path = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        # (one GPU per box in this pool; with several, rank r reads the r-th card that exposes a power sensor)
+        cands = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
+        if cands:
+            h = cands[min(device_index, len(cands) - 1)]
+            for f in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(h, f)):
+                    self.power_path = os.path.join(h, f)
+                    break
+            if os.path.exists(os.path.join(h, "freq1_input")):
+                self.sclk_path = os.path.join(h, "freq1_input")
+        self._threading = threading
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((time.perf_counter(), self._read(self.power_path) if self.power_path else None,
+                                 self._read(self.sclk_path) if self.sclk_path else None))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.power_path or self.sclk_path:
+            self._thr = self._threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+
+    def summary(self, t0, t1, what):
+        if not (self.power_path or self.sclk_path):
+            return {"error": "no amdgpu hwmon power / sclk sensor visible under /sys/class/drm", "region": what}
+        inside = [x for x in self.samples if t0 <= x[0] <= t1]
+        pw = [x[1] / 1e6 for x in inside if x[1] is not None]
+        ck = [x[2] / 1e6 for x in inside if x[2] is not None]
+        out = {"region": what, "samples": len(inside), "sensor": self.power_path or self.sclk_path}
+        if pw:
+            out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
+        if ck:
+            out.update(sclk_mhz_mean=sum(ck) / len(ck), sclk_mhz_min=min(ck), sclk_mhz_max=max(ck))
+        return out
+
+
+def library_source_digest(capi):
+    """`src=<12 hex>` of fa_build_info(): sha256 over kernel sources + headers + flags, stamped in by build.py"""
+    import re
+
+    m = re.search(r"src=([0-9a-f]+)", capi.lib().fa_build_info().decode())
+    return m.group(1) if m else None
+
+
 def hbm_traffic_from_profile(workload, kernel):
     """(bytes per launch, source) of the dominant kernel from the newest committed rocprofv3 PMC pass for this workload AND this
     kernel (profiles/rNN_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as
@@ -258,10 +345,11 @@ def hbm_traffic_from_profile(workload, kernel):
             with open(path) as f:
                 d = json.load(f)
             if d.get("workload") == workload and d.get("kernel", "fa_fwd_pp_kernel") == kernel:
-                return float(d["traffic_bytes_per_launch"]), f"committed profile {os.path.basename(path)} (not measured in this run)"
+                return (float(d["traffic_bytes_per_launch"]), f"committed profile {os.path.basename(path)} (not measured in this run)",
+                        d.get("library_source_digest"), d.get("git_commit"))
         except (OSError, ValueError, KeyError):
             pass
-    return None, f"no committed PMC profile for workload {workload} / kernel {kernel}"
+    return None, f"no committed PMC profile for workload {workload} / kernel {kernel}", None, None
 
 
 def parse_clockbench(out):
@@ -419,7 +507,13 @@ def main():
 
     # one rank per GPU; the modulo only matters when the harness itself is exercised with more ranks
     # than devices (e.g. --backend gloo with 2 ranks on a 1-GPU box)
-    device = torch.device("cuda", dist.local_rank % torch.cuda.device_count())
+    # --gpus N means N GPUs: say so before anything is allocated (FA_BENCH_ALLOW_OVERSUBSCRIBE=1 keeps the harness exercise of
+    # several ranks on one device, e.g. `--backend gloo` with 2 ranks on a 1-GPU box)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get("FA_BENCH_ALLOW_OVERSUBSCRIBE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} ROCm device(s) visible on this node "
+                         f"(rank {dist.rank}, LOCAL_RANK {dist.local_rank}); one rank per GPU is required")
+    device = torch.device("cuda", dist.local_rank % n_dev)
     torch.cuda.set_device(device)
     comm_backend = dist.try_nccl(device)
     b, s, h, hk, d, dtype, causal, backward = WORKLOADS[args.workload]
@@ -432,7 +526,17 @@ def main():
 
     sync = lambda: torch.cuda.synchronize(device)
     flops_rank = fwd_flops(b, s, s, h, d, causal) * (3.5 if backward else 1.0)
-    wall, _ = timed_region(step, args.steps, args.warmup, dist, sync, device)
+    with PowerSampler(device.index) as sampler:
+        wall, _ = timed_region(step, args.steps, args.warmup, dist, sync, device)
+        t_reg1 = time.perf_counter()
+        power_timed = sampler.summary(t_reg1 - wall, t_reg1, f"the timed region itself ({args.steps} steps, {wall * 1e3:.0f} ms)")
+        # the timed region of the default command is ~0.15 s; a 2 s loop of the same launch gives the sensors time to settle
+        t_s0 = time.perf_counter()
+        while time.perf_counter() - t_s0 < 2.0:
+            for _ in range(10):
+                step()
+            sync()
+        power_sustained = sampler.summary(t_s0 + 0.5, time.perf_counter(), "2 s of back-to-back launches of the same step right after the timed region (first 0.5 s dropped)")
     ms_per_step = wall / args.steps * 1e3
     value = flops_rank * dist.world / (wall / args.steps) / 1e12
 
@@ -441,13 +545,21 @@ def main():
     fwd_only = lambda: capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
     k_ms = event_time_ms(torch, fwd_only, max(5, args.steps))
     k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12
-    traffic, traffic_source = hbm_traffic_from_profile(args.workload, fwd_kernel) if dist.rank == 0 else (None, None)
+    k_dist = launch_time_distribution(torch, fwd_only, max(30, args.steps))
+    traffic, traffic_source, prof_digest, prof_commit = hbm_traffic_from_profile(args.workload, fwd_kernel) if dist.rank == 0 else (None, None, None, None)
+    lib_digest = library_source_digest(capi)
     prop = torch.cuda.get_device_properties(device)
     sclk_ghz = max(capi.device_clock_khz(device.index), 0) / 1e6     # hipDeviceAttributeClockRate (torch's props carry no clock)
     roofline = {"bound": "mfma", "kernel": fwd_kernel, "achieved": k_tflops, "peak": PEAK_DENSE_FP16_TFLOPS,
                 "unit": "TFLOP/s", "frac": k_tflops / PEAK_DENSE_FP16_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_source,
-                "avg_launch_ms": k_ms, "algorithmic_flops_per_launch": fwd_flops(b, s, s, h, d, causal),
+                "traffic_profile_library_digest": prof_digest, "traffic_profile_git_commit": prof_commit, "library_source_digest": lib_digest,
+                "profile_matches_library": (prof_digest == lib_digest) if prof_digest else None,
+                "avg_launch_ms": k_ms, "launch_ms_distribution": k_dist,
+                "tflops_at_median_launch": fwd_flops(b, s, s, h, d, causal) / k_dist["median_ms"] / 1e9,
+                "tflops_at_min_launch": fwd_flops(b, s, s, h, d, causal) / k_dist["min_ms"] / 1e9,
+                "power_and_sclk": {"timed_region": power_timed, "sustained": power_sustained},
+                "algorithmic_flops_per_launch": fwd_flops(b, s, s, h, d, causal),
                 "algorithmic_hbm_gbps": fwd_bytes(b, s, s, h, hk, d) / (k_ms * 1e-3) / 1e9,
                 "peak_derivation": {"cus": prop.multi_processor_count, "sclk_ghz": sclk_ghz, "flop_per_clk_per_cu": MFMA_FLOP_PER_CLK_PER_CU,
                                     "cus_x_sclk_x_4096_tflops": prop.multi_processor_count * sclk_ghz * MFMA_FLOP_PER_CLK_PER_CU / 1e3}}
@@ -559,6 +671,9 @@ def main():
         roofline["sustained_mfma_peak_measured"] = ceiling          # carries {"error": ...} instead of vanishing if clockbench fails
         if "tflops" in ceiling:
             roofline["frac_of_sustained_measured"] = k_tflops / ceiling["tflops"]
+    if dist.rank == 0 and prof_digest and prof_digest != lib_digest:
+        roofline["warning"] = (f"roofline.traffic comes from a profile of library build src={prof_digest}, this run timed src={lib_digest}: "
+                               "re-run tools/round_evidence.sh on the current kernels")
     if dist.rank == 0:
         out = {
             "metric": "attention_fwd_tflops" if not backward else "attention_fwd_bwd_tflops",
@@ -571,7 +686,7 @@ def main():
                        "global_batch": b * dist.world, "seq_len": s, "parallelism": f"batch-sharded x{dist.world}, no collective",
                        "flops_def": "4*b*h*sq*sk*d (x0.5 causal) [SURVEY.md 8d]"},
             "frac_of_fp16_mfma_peak": value / (PEAK_DENSE_FP16_TFLOPS * dist.world),
-            "comm_backend": comm_backend,
+            "comm_backend": comm_backend, "library": capi.lib().fa_build_info().decode(),
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
             "device": {"name": prop.name or getattr(prop, "gcnArchName", ""), "arch": getattr(prop, "gcnArchName", ""), "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,
                        "peak_used_tflops": PEAK_DENSE_FP16_TFLOPS},

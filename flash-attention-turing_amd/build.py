@@ -80,6 +80,9 @@ def build_kernels(force=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     stamp = _digest(srcs + hdrs, " ".join(HIPCC_FLAGS) + repr(sorted(EXTRA_FLAGS.items())))
+    # the same digest goes INTO the library (fa_build_info()): a profile summary records it, bench.py compares it with the library
+    # it is timing, so a committed rocprof table can be tied to the kernels that produced it
+    digest_flag = f'-DFA_SOURCE_DIGEST="{stamp[:12]}"'
     if not force and not _stale(LIB_PATH, stamp):
         print(f"[build] {LIB_NAME} up to date")
         return LIB_PATH
@@ -90,6 +93,8 @@ def build_kernels(force=False):
         o = s[:-4] + ".o"
         objs.append(o)
         cmd = [hipcc_path()] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-I", CSRC, "-I", INCLUDE, "-c", s, "-o", o]
+        if os.path.basename(s) == "fa_capi.hip":
+            cmd.insert(1, digest_flag)
         print("[build]", " ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))
     for p in procs:

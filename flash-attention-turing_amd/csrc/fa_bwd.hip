@@ -9,7 +9,8 @@
 //   fa_bwd_sum_splits_kernel  adds the fp32 partial dK / dV planes when the dK/dV launch split a GQA head group (C ABI 3)
 //
 // A backward call is TWO launches on one stream, dQ then dK/dV (plus the plane sum when split): the dQ kernel computes D for
-// its own rows in its prologue and leaves it in the workspace for dK/dV; the stand-alone dot_do_o kernel stays as an entry point.
+// its own rows in its prologue and leaves it in dsoftmax_sum for dK/dV; the stand-alone dot_do_o kernel stays as an entry point.
+// ("workspace" below always means the optional fp32 dK / dV scratch of C ABI 3, never D.)
 //
 // Like the reference this is the deterministic, atomics-free 7-GEMM form (S and dP are
 // recomputed in both kernels).  Differences that matter on CDNA4:
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
         dof[ks] = buf_load16(do_rs, (uint32_t)q_row * do_rowb + (2 * ks + hi) * 16);
     }
     // D_i = rowsum(dO_i * O_i) (flash_bwd_preprocess_kernel.h:23-96) is computed HERE, from the dO fragments this lane holds anyway and the
-    // matching O fragments (one extra 64 KiB read per workgroup, hidden behind the first K / V tiles), and written to the workspace for
+    // matching O fragments (one extra 64 KiB read per workgroup, hidden behind the first K / V tiles), and written to dsoftmax_sum for
     // the dK/dV launch that follows on the stream: the separate fa_bwd_dot_do_o launch (0.09 ms at C4, ~6 % of a 512-long backward) is
     // no longer on the path of fa_run_mha_bwd.  fp32 products and sums, like the stand-alone kernel.
     float lse2 = 0.f, dsum = 0.f;   // rows past the end keep 0 (they contribute nothing: Q = dO = 0)
@@ -809,11 +810,27 @@ static int64_t dkdv_rows(const BwdKernelParams& kp) { return kp.cu_seqlens_k != 
 int64_t dkdv_workspace_bytes(const BwdKernelParams& kp, int32_t n_split) {
     return n_split <= 1 ? 0 : 2 * (int64_t)n_split * dkdv_rows(kp) * kp.h_k * kp.d * 4;
 }
+// CUs of the current device (the split target is "workgroups per CU"); 256 = MI355X when there is no device (host-only callers).
+static int64_t device_cu_count() {
+    static const int64_t cached = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();                     // a box without a GPU: do not leave a sticky error behind
+            return (int64_t)256;
+        }
+        return (int64_t)n;
+    }();
+    return cached;
+}
 int32_t dkdv_split(const BwdKernelParams& kp, int64_t avail_bytes) {
     if (kp.h_ratio <= 1 || dkdv_rows(kp) <= 0) return 1;
     const int64_t n_k_tiles = (kp.seqlen_k + kKvBlockN - 1) / kKvBlockN;
-    const int64_t wgs = (kp.cu_seqlens_k != nullptr ? (int64_t)varlen_slot_count(kp.total_k, kp.b, kKvBlockN, (uint32_t)n_k_tiles) : n_k_tiles * kp.b) * kp.h_k;
-    const int64_t want = kp.is_causal ? FA_KV_SPLIT_CAUSAL_PER_CU * 256 : 256;
+    // workgroups of the unsplit launch, exactly as launch_dkdv_t sizes its grid: varlen_slot_count() == 0 means "the plain
+    // tiles x batch grid" (uniform lengths, batches past kVarlenMaxBatch), not "no workgroups"
+    const int64_t slots = kp.cu_seqlens_k != nullptr ? (int64_t)varlen_slot_count(kp.total_k, kp.b, kKvBlockN, (uint32_t)n_k_tiles) : 0;
+    const int64_t wgs = (slots != 0 ? slots : n_k_tiles * kp.b) * kp.h_k;
+    const int64_t cus = device_cu_count();
+    const int64_t want = kp.is_causal ? FA_KV_SPLIT_CAUSAL_PER_CU * cus : cus;
     int32_t split = 1;
     while (split * 2 <= kp.h_ratio && kp.h_ratio % (split * 2) == 0 && wgs * split < want &&
            (avail_bytes < 0 || dkdv_workspace_bytes(kp, split * 2) <= avail_bytes))

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -50,6 +51,22 @@ int check_common(int b, int sq, int sk, int h, int hk, int d, int dtype) {
     return FA_OK;
 }
 
+// ABI 4: the caller's struct -> a zeroed local one, min(caller's size, ours) bytes.  Fields appended after the caller's header was
+// written stay 0 / NULL ("not given"); a struct without the {size, magic} header (ABI 1-3 callers) or longer than ours is an error.
+template <typename P>
+int import_params(const P* user, P& local, const char* what) {
+    if (user == nullptr) return fail(FA_ERR_NULL_POINTER, "params is NULL");
+    if (user->magic != FA_PARAMS_MAGIC)
+        return fail(FA_ERR_BAD_ABI, "%s: no {struct_size, magic} header - caller was compiled against an ABI < 4 header; recompile against include/flash_attn_gfx950.h (ABI %d)",
+                    what, FA_ABI_VERSION);
+    const size_t base = offsetof(P, total_q);           // everything up to the first appended (optional) field is mandatory
+    if (user->struct_size < base || user->struct_size > sizeof(P))
+        return fail(FA_ERR_BAD_ABI, "%s: struct_size %u outside [%zu, %zu] - header / library mismatch", what, user->struct_size, base, sizeof(P));
+    memset(&local, 0, sizeof(P));
+    memcpy(&local, user, user->struct_size);
+    return FA_OK;
+}
+
 int hip_status(hipError_t e, const char* what) {
     if (e == hipSuccess) return FA_OK;
     fail((int)e, "%s: %s", what, hipGetErrorString(e));
@@ -65,7 +82,10 @@ const char* fa_last_error(void) { return g_err; }
 
 #define FA_STR2(x) #x
 #define FA_STR(x) FA_STR2(x)
-const char* fa_build_info(void) { return "flash_attn_gfx950 abi=" FA_STR(FA_ABI_VERSION) " arch=gfx950 mfma=32x32x16 wave64 built " __DATE__; }
+#ifndef FA_SOURCE_DIGEST
+#define FA_SOURCE_DIGEST "unstamped"      // build.py passes the first 12 hex digits of the sha256 over kernel sources, headers and flags
+#endif
+const char* fa_build_info(void) { return "flash_attn_gfx950 abi=" FA_STR(FA_ABI_VERSION) " arch=gfx950 mfma=32x32x16 wave64 src=" FA_SOURCE_DIGEST " built " __DATE__; }
 
 double fa_fwd_flops(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t d, int32_t is_causal) {
     double pairs;
@@ -99,9 +119,12 @@ int fa_device_clock_khz(int32_t device) {
     return e == hipSuccess ? khz : -(int)e;
 }
 
-int fa_run_mha_fwd(const fa_fwd_params* p, void* stream) {
-    if (p == nullptr) return fail(FA_ERR_NULL_POINTER, "params is NULL");
-    int rc = check_common(p->b, p->seqlen_q, p->seqlen_k, p->h, p->h_k, p->d, p->dtype);
+int fa_run_mha_fwd(const fa_fwd_params* user, void* stream) {
+    fa_fwd_params local;
+    int rc = import_params(user, local, "fa_fwd_params");
+    if (rc) return rc;
+    const fa_fwd_params* p = &local;
+    rc = check_common(p->b, p->seqlen_q, p->seqlen_k, p->h, p->h_k, p->d, p->dtype);
     if (rc) return rc;
     const bool varlen = p->cu_seqlens_q != nullptr || p->cu_seqlens_k != nullptr;
     if (varlen && (p->cu_seqlens_q == nullptr || p->cu_seqlens_k == nullptr))
@@ -130,9 +153,12 @@ int fa_run_mha_fwd(const fa_fwd_params* p, void* stream) {
     return hip_status(fa::launch_fwd(kp, p->dtype, (hipStream_t)stream), "fa_fwd launch");
 }
 
-static int fill_bwd(const fa_bwd_params* p, fa::BwdKernelParams& kp) {
-    if (p == nullptr) return fail(FA_ERR_NULL_POINTER, "params is NULL");
-    int rc = check_common(p->b, p->seqlen_q, p->seqlen_k, p->h, p->h_k, p->d, p->dtype);
+// with_workspace = false: the `workspace` fields are not looked at (fa_bwd_workspace_bytes, and the launches that never use it)
+static int fill_bwd(const fa_bwd_params* user, fa::BwdKernelParams& kp, fa_bwd_params& local, bool with_workspace) {
+    int rc = import_params(user, local, "fa_bwd_params");
+    if (rc) return rc;
+    const fa_bwd_params* p = &local;
+    rc = check_common(p->b, p->seqlen_q, p->seqlen_k, p->h, p->h_k, p->d, p->dtype);
     if (rc) return rc;
     const bool varlen = p->cu_seqlens_q != nullptr || p->cu_seqlens_k != nullptr;
     if (varlen && (p->cu_seqlens_q == nullptr || p->cu_seqlens_k == nullptr))
@@ -165,8 +191,8 @@ static int fill_bwd(const fa_bwd_params* p, fa::BwdKernelParams& kp) {
     if (p->cu_seqlens_q != nullptr) { kp.total_q = p->total_q; kp.total_k = p->total_k; }
     kp.scale = 1.0f / sqrtf((float)p->d);
     kp.scale_log2e = kp.scale * 1.4426950408889634f;
-    if (p->workspace_bytes < 0) return fail(FA_ERR_BAD_SHAPE, "workspace_bytes must be >= 0");
-    if (p->workspace != nullptr && p->workspace_bytes > 0) {
+    if (with_workspace && p->workspace_bytes < 0) return fail(FA_ERR_BAD_SHAPE, "workspace_bytes must be >= 0");
+    if (with_workspace && p->workspace != nullptr && p->workspace_bytes > 0) {
         if ((reinterpret_cast<uintptr_t>(p->workspace) & 15u) != 0) return fail(FA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
         kp.ws = (float*)p->workspace; kp.ws_bytes = p->workspace_bytes;
     }
@@ -174,42 +200,52 @@ static int fill_bwd(const fa_bwd_params* p, fa::BwdKernelParams& kp) {
     return FA_OK;
 }
 
-int64_t fa_bwd_workspace_bytes(const fa_bwd_params* p) {
+int64_t fa_bwd_workspace_bytes(const fa_bwd_params* user) {
     fa::BwdKernelParams kp;
-    int rc = fill_bwd(p, kp);
+    fa_bwd_params local;
+    int rc = fill_bwd(user, kp, local, false);
     if (rc) return rc;
+    const fa_bwd_params* p = &local;
     if (p->b == 0 || p->seqlen_k == 0 || p->seqlen_q == 0) return 0;
     return fa::dkdv_workspace_bytes(kp, fa::dkdv_split(kp, -1));
 }
 
-int fa_bwd_dot_do_o(const fa_bwd_params* p, void* stream) {
+int fa_bwd_dot_do_o(const fa_bwd_params* user, void* stream) {
     fa::BwdKernelParams kp;
-    int rc = fill_bwd(p, kp);
+    fa_bwd_params local;
+    int rc = fill_bwd(user, kp, local, false);
     if (rc) return rc;
+    const fa_bwd_params* p = &local;
     if (p->b == 0 || p->seqlen_q == 0) return FA_OK;
     return hip_status(fa::launch_bwd_dot_do_o(kp, p->dtype, (hipStream_t)stream), "fa_bwd_dot_do_o launch");
 }
 
-int fa_bwd_dq(const fa_bwd_params* p, void* stream) {
+int fa_bwd_dq(const fa_bwd_params* user, void* stream) {
     fa::BwdKernelParams kp;
-    int rc = fill_bwd(p, kp);
+    fa_bwd_params local;
+    int rc = fill_bwd(user, kp, local, false);
     if (rc) return rc;
+    const fa_bwd_params* p = &local;
     if (p->b == 0 || p->seqlen_q == 0) return FA_OK;
     return hip_status(fa::launch_bwd_dq(kp, p->dtype, (hipStream_t)stream), "fa_bwd_dq launch");
 }
 
-int fa_bwd_dkdv(const fa_bwd_params* p, void* stream) {
+int fa_bwd_dkdv(const fa_bwd_params* user, void* stream) {
     fa::BwdKernelParams kp;
-    int rc = fill_bwd(p, kp);
+    fa_bwd_params local;
+    int rc = fill_bwd(user, kp, local, true);
     if (rc) return rc;
+    const fa_bwd_params* p = &local;
     if (p->b == 0 || p->seqlen_k == 0) return FA_OK;
     return hip_status(fa::launch_bwd_dkdv(kp, p->dtype, (hipStream_t)stream), "fa_bwd_dkdv launch");
 }
 
-int fa_run_mha_bwd(const fa_bwd_params* p, void* stream) {
+int fa_run_mha_bwd(const fa_bwd_params* user, void* stream) {
     fa::BwdKernelParams kp;
-    int rc = fill_bwd(p, kp);
+    fa_bwd_params local;
+    int rc = fill_bwd(user, kp, local, true);
     if (rc) return rc;
+    const fa_bwd_params* p = &local;
     if (p->b == 0) return FA_OK;
     hipStream_t s = (hipStream_t)stream;
     // The reference's run_flash_bwd launches dot_do_o, dQ, dK/dV (flash_bwd_launch_template.h:69-146).  Here the dQ kernel computes
@@ -228,7 +264,7 @@ int fa_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, int32_t d,
                int32_t dtype, int32_t is_causal, void* stream) {
     fa_fwd_params p;
-    memset(&p, 0, sizeof(p));
+    FA_PARAMS_INIT(p);
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
     p.b = b; p.seqlen_q = sq; p.seqlen_k = sk; p.h = h; p.h_k = hk; p.d = d; p.dtype = dtype; p.is_causal = is_causal;
     p.q_stride = contiguous_bshd(sq, h, d); p.o_stride = p.q_stride;
@@ -242,7 +278,7 @@ int fa_mha_varlen_fwd(const void* q, const void* k, const void* v, void* o, floa
                       int32_t dtype, int32_t is_causal, void* stream) {
     if (cu_q == nullptr || cu_k == nullptr) return fail(FA_ERR_NULL_POINTER, "cu_seqlens_q/cu_seqlens_k must not be NULL");
     fa_fwd_params p;
-    memset(&p, 0, sizeof(p));
+    FA_PARAMS_INIT(p);
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.cu_seqlens_q = cu_q; p.cu_seqlens_k = cu_k;
     p.b = b; p.seqlen_q = max_sq; p.seqlen_k = max_sk; p.h = h; p.h_k = hk; p.d = d; p.dtype = dtype; p.is_causal = is_causal;
     p.q_stride = fa_strides{0, (int64_t)h * d, d}; p.o_stride = p.q_stride;
@@ -255,7 +291,7 @@ int fa_mha_bwd(const void* q, const void* k, const void* v, const void* o, const
                int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, int32_t d,
                int32_t dtype, int32_t is_causal, void* stream) {
     fa_bwd_params p;
-    memset(&p, 0, sizeof(p));
+    FA_PARAMS_INIT(p);
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.dsoftmax_sum = dsum;
     p.b = b; p.seqlen_q = sq; p.seqlen_k = sk; p.h = h; p.h_k = hk; p.d = d; p.dtype = dtype; p.is_causal = is_causal;
     p.q_stride = contiguous_bshd(sq, h, d); p.o_stride = p.do_stride = p.dq_stride = p.q_stride;
@@ -270,7 +306,7 @@ int fa_mha_varlen_bwd(const void* q, const void* k, const void* v, const void* o
                       int32_t dtype, int32_t is_causal, void* stream) {
     if (cu_q == nullptr || cu_k == nullptr) return fail(FA_ERR_NULL_POINTER, "cu_seqlens_q/cu_seqlens_k must not be NULL");
     fa_bwd_params p;
-    memset(&p, 0, sizeof(p));
+    FA_PARAMS_INIT(p);
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv; p.dsoftmax_sum = dsum;
     p.cu_seqlens_q = cu_q; p.cu_seqlens_k = cu_k;
     p.b = b; p.seqlen_q = max_sq; p.seqlen_k = max_sk; p.h = h; p.h_k = hk; p.d = d; p.dtype = dtype; p.is_causal = is_causal;

@@ -13,6 +13,8 @@
 // device 0), launch errors surfaced.  This file contains no device code: it is compiled by
 // plain g++ and calls the C ABI in include/flash_attn_gfx950.h; PyTorch is only plumbing
 // (allocation, streams).
+#include <atomic>
+
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
@@ -56,14 +58,14 @@ fa_strides strides3(const at::Tensor& t) {
 // NOTE: the densifying copy is a hidden extra HBM pass the reference never makes (it never checks); it only
 // triggers for layouts the kernels cannot address (unaligned base / strides, broadcast rows) and is counted in
 // g_densify_copies (exported as `densify_copies()`) so that a caller can see it happened.
-int64_t g_densify_copies = 0;
+std::atomic<int64_t> g_densify_copies{0};       // autograd may run backward on several threads / devices at once
 at::Tensor dense_last(const at::Tensor& t) {
     bool ok = t.stride(-1) == 1 && (reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0);
     for (int i = 0; i < t.dim() - 1 && ok; ++i) ok = (t.stride(i) % 8 == 0);
     // the row (sequence) dimension is dim -3: an expand()-ed / overlapping row stride (< head_dim) is not addressable
     if (ok && t.dim() >= 3 && t.size(-3) > 1) ok = t.stride(-3) >= t.size(-1);
     if (ok) return t;
-    ++g_densify_copies;
+    g_densify_copies.fetch_add(1, std::memory_order_relaxed);
     return t.contiguous();
 }
 void check_same_device(const at::Tensor& q, const at::Tensor& t, const char* name) {
@@ -100,7 +102,8 @@ std::vector<at::Tensor> mha_fwd(at::Tensor q, at::Tensor k, at::Tensor v, bool i
     at::Tensor o = torch::empty(q.sizes(), q.options());
     at::Tensor l = torch::empty({batch_size, num_heads, seqlen_q}, q.options().dtype(torch::kFloat32));
 
-    fa_fwd_params p{};
+    fa_fwd_params p;
+    FA_PARAMS_INIT(p);
     p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr(); p.o = o.data_ptr(); p.lse = l.data_ptr<float>();
     p.b = (int32_t)batch_size; p.seqlen_q = (int32_t)seqlen_q; p.seqlen_k = (int32_t)seqlen_k;
     p.h = (int32_t)num_heads; p.h_k = (int32_t)num_heads_k; p.d = (int32_t)head_size;
@@ -137,7 +140,8 @@ std::vector<at::Tensor> mha_bwd(at::Tensor q, at::Tensor k, at::Tensor v, at::Te
     at::Tensor dv = torch::empty(v.sizes(), v.options());
     at::Tensor do_o = torch::empty_like(l);   // D = rowsum(dO * O), the reference's do_o (:274)
 
-    fa_bwd_params p{};
+    fa_bwd_params p;
+    FA_PARAMS_INIT(p);
     p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr(); p.o = out.data_ptr(); p.dout = dout.data_ptr();
     p.lse = l.data_ptr<float>(); p.dsoftmax_sum = do_o.data_ptr<float>();
     p.dq = dq.data_ptr(); p.dk = dk.data_ptr(); p.dv = dv.data_ptr();
@@ -146,7 +150,7 @@ std::vector<at::Tensor> mha_bwd(at::Tensor q, at::Tensor k, at::Tensor v, at::Te
     p.dtype = fa_dtype_of(q); p.is_causal = is_causal;
     p.q_stride = strides4(q); p.k_stride = strides4(k); p.v_stride = strides4(v); p.o_stride = strides4(out);
     p.do_stride = strides4(dout); p.dq_stride = strides4(dq); p.dk_stride = strides4(dk); p.dv_stride = strides4(dv);
-    // ABI 3: fp32 scratch that lets the dK/dV launch split a KV head's query-head group over several workgroups (GQA / MQA with few
+    // fp32 scratch (ABI 3) that lets the dK/dV launch split a KV head's query-head group over several workgroups (GQA / MQA with few
     // workgroups, causal imbalance); 0 bytes for MHA and for grids that fill the chip anyway
     at::Tensor workspace;
     const int64_t ws_bytes = fa_bwd_workspace_bytes(&p);
@@ -185,7 +189,8 @@ std::vector<at::Tensor> mha_varlen_fwd(at::Tensor q, at::Tensor k, at::Tensor v,
     // reference's zero fill for those (flash_api.cpp:352)
     at::Tensor l = torch::zeros({batch_size, num_heads, max_seqlen_q}, q.options().dtype(torch::kFloat32));
 
-    fa_fwd_params p{};
+    fa_fwd_params p;
+    FA_PARAMS_INIT(p);
     p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr(); p.o = out.data_ptr(); p.lse = l.data_ptr<float>();
     p.cu_seqlens_q = cu_seqlens_q.data_ptr<int32_t>(); p.cu_seqlens_k = cu_seqlens_k.data_ptr<int32_t>();
     p.b = (int32_t)batch_size; p.seqlen_q = max_seqlen_q; p.seqlen_k = max_seqlen_k;
@@ -231,7 +236,8 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     at::Tensor dv = torch::zeros_like(v);
     at::Tensor do_o = torch::zeros_like(l);
 
-    fa_bwd_params p{};
+    fa_bwd_params p;
+    FA_PARAMS_INIT(p);
     p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr(); p.o = out.data_ptr(); p.dout = dout.data_ptr();
     p.lse = l.data_ptr<float>(); p.dsoftmax_sum = do_o.data_ptr<float>();
     p.dq = dq.data_ptr(); p.dk = dk.data_ptr(); p.dv = dv.data_ptr();
@@ -242,7 +248,7 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     p.q_stride = strides3(q); p.k_stride = strides3(k); p.v_stride = strides3(v); p.o_stride = strides3(out);
     p.do_stride = strides3(dout); p.dq_stride = strides3(dq); p.dk_stride = strides3(dk); p.dv_stride = strides3(dv);
     p.total_q = q.size(0); p.total_k = k.size(0);
-    // ABI 3: fp32 scratch that lets the dK/dV launch split a KV head's query-head group over several workgroups (GQA / MQA with few
+    // fp32 scratch (ABI 3) that lets the dK/dV launch split a KV head's query-head group over several workgroups (GQA / MQA with few
     // workgroups, causal imbalance); 0 bytes for MHA and for grids that fill the chip anyway
     at::Tensor workspace;
     const int64_t ws_bytes = fa_bwd_workspace_bytes(&p);
@@ -263,5 +269,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("varlen_bwd", &mha_varlen_bwd, "Varlen backward pass");
     m.def("abi_version", []() { return fa_abi_version(); });
     m.def("build_info", []() { return std::string(fa_build_info()); });
-    m.def("densify_copies", []() { return g_densify_copies; }, "number of hidden .contiguous() copies made so far (0 for addressable layouts)");
+    m.def("densify_copies", []() { return g_densify_copies.load(std::memory_order_relaxed); }, "number of hidden .contiguous() copies made so far (0 for addressable layouts)");
 }

@@ -16,6 +16,8 @@ HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "
 FA_FP16, FA_BF16 = 0, 1
 FA_OK = 0
 FA_ERR_NULL_POINTER, FA_ERR_BAD_SHAPE, FA_ERR_BAD_GQA, FA_ERR_BAD_HEADDIM, FA_ERR_BAD_DTYPE, FA_ERR_BAD_STRIDE = -1, -2, -3, -4, -5, -6
+FA_ERR_BAD_ABI = -8
+FA_PARAMS_MAGIC = 0xFA950A71      # include/flash_attn_gfx950.h
 
 _vp, _i32, _fp = ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p
 
@@ -24,8 +26,16 @@ class Strides(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int64), ("row", ctypes.c_int64), ("head", ctypes.c_int64)]
 
 
-class FwdParams(ctypes.Structure):
-    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("lse", _vp),
+class _Params(ctypes.Structure):
+    """ABI 4: every params struct starts with {struct_size, magic}; the constructor fills them like FA_PARAMS_INIT"""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size, self.magic = ctypes.sizeof(type(self)), FA_PARAMS_MAGIC
+
+
+class FwdParams(_Params):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("magic", ctypes.c_uint32), ("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("lse", _vp),
                 ("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp),
                 ("b", _i32), ("seqlen_q", _i32), ("seqlen_k", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
                 ("dtype", _i32), ("is_causal", _i32),
@@ -33,8 +43,8 @@ class FwdParams(ctypes.Structure):
                 ("total_q", ctypes.c_int64), ("total_k", ctypes.c_int64)]      # ABI 2, optional (0 = unknown)
 
 
-class BwdParams(ctypes.Structure):
-    _fields_ = [("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("dout", _vp), ("lse", _vp),
+class BwdParams(_Params):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("magic", ctypes.c_uint32), ("q", _vp), ("k", _vp), ("v", _vp), ("o", _vp), ("dout", _vp), ("lse", _vp),
                 ("dq", _vp), ("dk", _vp), ("dv", _vp), ("dsoftmax_sum", _vp),
                 ("cu_seqlens_q", _vp), ("cu_seqlens_k", _vp),
                 ("b", _i32), ("seqlen_q", _i32), ("seqlen_k", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
@@ -172,7 +182,8 @@ def attach_workspace(params, like):
 
 
 def run_bwd(params, stream=None):
-    """the whole backward (dot_do_o, dQ, dK/dV) from a parameter struct, e.g. one with a workspace attached"""
+    """the whole backward from a parameter struct, e.g. one with a workspace attached: dQ (which also computes D = rowsum(dO * O)
+    into dsoftmax_sum), then dK/dV (+ the plane sum when the head group was split through the workspace)"""
     import torch
 
     s = torch.cuda.current_stream().cuda_stream if stream is None else stream

@@ -23,7 +23,7 @@ class FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = _C.bwd(q, k, v, out, lse, dout.contiguous(), ctx.causal)
+        dq, dk, dv = _C.bwd(q, k, v, out, lse, dout, ctx.causal)      # strided dout is fine: the kernels take real strides
         return dq, dk, dv, None
 
 
@@ -41,7 +41,7 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
     def backward(ctx, dout):
         q, k, v, out, lse, cu_q, cu_k = ctx.saved_tensors
         max_q, max_k, causal = ctx.meta
-        dq, dk, dv = _C.varlen_bwd(q, k, v, out, lse, dout.contiguous(), cu_q, cu_k, max_q, max_k, causal)
+        dq, dk, dv = _C.varlen_bwd(q, k, v, out, lse, dout, cu_q, cu_k, max_q, max_k, causal)
         return dq, dk, dv, None, None, None, None, None
 
 

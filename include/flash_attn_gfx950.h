@@ -41,12 +41,22 @@
 #define FLASH_ATTN_GFX950_H
 
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 3   /* 2: optional total_q / total_k appended to fa_fwd_params / fa_bwd_params; 3: optional workspace appended to fa_bwd_params */
+#define FA_ABI_VERSION 4   /* 2: optional total_q / total_k appended to fa_fwd_params / fa_bwd_params; 3: optional workspace appended to
+                              fa_bwd_params; 4: both structs start with {struct_size, magic}, appended fields are read only if the caller's
+                              struct holds them */
+/* Every params struct starts with its own size AS THE CALLER COMPILED IT and this constant.  The library copies min(struct_size,
+ * its own sizeof) bytes into a zeroed local struct: a caller built against an older ABI >= 4 header simply leaves the fields appended
+ * since then at their defaults (0 / NULL = "not given"), and a caller built against an ABI 1-3 header (no size field: its first 8
+ * bytes are the q pointer, whose upper half can never equal the magic) is rejected with FA_ERR_BAD_ABI instead of having the library
+ * read past the end of its struct.  FA_PARAMS_INIT(p) zeroes a struct and fills both fields. */
+#define FA_PARAMS_MAGIC 0xFA950A71u
+#define FA_PARAMS_INIT(p) do { memset(&(p), 0, sizeof(p)); (p).struct_size = (uint32_t)sizeof(p); (p).magic = FA_PARAMS_MAGIC; } while (0)
 
 enum fa_dtype { FA_FP16 = 0, FA_BF16 = 1 };
 
@@ -58,7 +68,9 @@ enum fa_status {
     FA_ERR_BAD_HEADDIM = -4,     /* head_dim not in {64,128} */
     FA_ERR_BAD_DTYPE = -5,
     FA_ERR_BAD_STRIDE = -6,      /* last dim not contiguous, misaligned rows, or extent > 2^31 bytes per sequence */
-    FA_ERR_NO_DEVICE = -7
+    FA_ERR_NO_DEVICE = -7,
+    FA_ERR_BAD_ABI = -8          /* params struct without a valid {struct_size, magic} header, shorter than the ABI 4 base, or longer
+                                    than this library knows (caller compiled against a newer header) */
 };
 
 /* Element strides (NOT bytes). The innermost (head_dim) stride is 1 by contract. */
@@ -70,6 +82,8 @@ typedef struct fa_strides {
 
 /* Mirrors Qkv_params + Flash_fwd_params (reference src/flash.h:6-52). */
 typedef struct fa_fwd_params {
+    uint32_t struct_size;       /* sizeof(fa_fwd_params) in the caller's translation unit */
+    uint32_t magic;             /* FA_PARAMS_MAGIC */
     const void* q;
     const void* k;
     const void* v;
@@ -96,6 +110,8 @@ typedef struct fa_fwd_params {
 
 /* Mirrors Flash_bwd_params (reference src/flash.h:55-76). */
 typedef struct fa_bwd_params {
+    uint32_t struct_size;       /* sizeof(fa_bwd_params) in the caller's translation unit */
+    uint32_t magic;             /* FA_PARAMS_MAGIC */
     const void* q;
     const void* k;
     const void* v;
@@ -105,7 +121,7 @@ typedef struct fa_bwd_params {
     void* dq;
     void* dk;                   /* (b, seqlen_k, h_k, d): already summed over the GQA group */
     void* dv;
-    float* dsoftmax_sum;        /* workspace D = rowsum(dO*O), same shape as lse (the reference's do_o) */
+    float* dsoftmax_sum;        /* D = rowsum(dO*O), same shape as lse (the reference's do_o): written by the dQ launch, read by dK/dV */
     const int32_t* cu_seqlens_q;
     const int32_t* cu_seqlens_k;
     int32_t b;
@@ -173,8 +189,9 @@ int fa_bwd_dot_do_o(const fa_bwd_params* params, void* stream);
  * profiled against its own roofline (bench.py `roofline_bwd`). */
 int fa_bwd_dq(const fa_bwd_params* params, void* stream);
 int fa_bwd_dkdv(const fa_bwd_params* params, void* stream);
-/* Bytes of fa_bwd_params.workspace the dK/dV launch of these params would use (0: it would not split; the `workspace` fields of
- * the argument are ignored).  Host-only arithmetic.  Negative = error code. */
+/* Bytes of fa_bwd_params.workspace the dK/dV launch of these params would use (0: it would not split).  The `workspace` /
+ * `workspace_bytes` fields of the argument are ignored (a stale or unaligned pointer left in a reused struct is not an error here).
+ * Host-only arithmetic; the split target follows the CU count of the current device (256 when there is none).  Negative = error code. */
 int64_t fa_bwd_workspace_bytes(const fa_bwd_params* params);
 
 /* ---- measurement helpers ----------------------------------------------------------------- */

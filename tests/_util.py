@@ -64,7 +64,55 @@ def _record_margin(name, raw, dtype, plain):
     slot["plain_bound_cases"] += int(plain)
 
 
-def assert_close(x, ref, dtype, name, scale=1.0, sk=None):
+REL_TABLE = []   # one row per mean_rel decision (family, case, tensor, dtype, kernel / oracle raw mean_rel, bound, rule) -> gpurun_out/mean_rel_table.json
+
+
+def raw_mean_rel(x, e):
+    """The reference's plain metric (test_flash_attn.py:51-71): mean(|x - e| / max(|e|, 1e-6))."""
+    x, e = np.asarray(x, dtype=np.float64), np.asarray(e, dtype=np.float64)
+    return float((np.abs(x - e) / np.maximum(np.abs(e), REL_EPS)).mean()) if x.size else 0.0
+
+
+def check_mean_rel(xa, e, dtype, name, scale, sk, oracle):
+    """mean_rel, the reference's third bound (test_flash_attn.py:117,412: plain mean(|d| / max(|ref|, 1e-6)) <= 1e-2), asserted RAW:
+      rule "oracle": the caller supplied the C oracle's result (the reference ALGORITHM in contract mode: P / dS / outputs rounded
+                     where the reference rounds them, everything else exact) for the same tensor.  Bound = max(1e-2, 2 x the
+                     oracle's own raw mean_rel against the same expectation): where the reference algorithm itself meets 1e-2 the
+                     kernel must meet the plain bound, where it provably cannot (a handful of keys: nothing averages the rounding of
+                     P / dS out; tools/mean_rel_oracle_table.py prints the oracle's side on the dev container) the kernel may be
+                     at most twice as far off as the algorithm is.
+      rule "plain":  no oracle result (large problems) and sk >= 64: the plain bound.
+      rule "zero":   the expectation is identically ~0 (max |e| < 1e-4): a single visible key makes dS = P (dP - D) vanish
+                     analytically, the oracle returns exact zeros, and ANY fp32 implementation that forms D = rowsum(dO * O) and
+                     dP = dO . V in different summation orders (the reference's own dot_do_o + tensor-core dP included) leaves
+                     ~1e-7 of noise whose relative error against 0 is unbounded: recorded, not asserted.
+      rule "floor":  neither (sk < 64 without an oracle result): elements below 1 % of the tensor's RMS are measured against 1 % of
+                     the RMS instead of against (nearly) zero.
+    Every decision is appended to REL_TABLE."""
+    tol = TOL[dtype]["mean_rel"] * scale
+    fam = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split("::")[-1].split(" ")[0]
+    k_raw = raw_mean_rel(xa, e)
+    row = dict(family=fam, case=name, dtype=dtype, kernel=k_raw, oracle=None, bound=None, rule=None)
+    REL_TABLE.append(row)
+    if float(np.abs(e).max(initial=0.0)) < 1e-4:
+        row.update(rule="zero")
+        return
+    if oracle is not None:
+        o_raw = raw_mean_rel(np.asarray(oracle, dtype=np.float64), e)
+        bound = max(tol, 2.0 * o_raw)
+        row.update(rule="oracle", oracle=o_raw, bound=bound)
+        assert k_raw <= bound, f"{name} raw mean_rel={k_raw:.3e} > max({tol:.1e}, 2 x oracle's {o_raw:.3e})"
+    elif sk is not None and sk >= PLAIN_SK_MIN:
+        row.update(rule="plain", bound=tol)
+        assert k_raw <= tol, f"{name} PLAIN mean_rel={k_raw:.3e} > {tol:.1e} (sk={sk})"
+    else:
+        floor = max(REL_EPS, 0.01 * float(np.sqrt(np.mean(e * e))))
+        m_rel = float((np.abs(xa - e) / np.maximum(np.abs(e), floor)).mean())
+        row.update(rule="floor", bound=tol, floored=m_rel)
+        assert m_rel <= tol, f"{name} mean_rel(floor {floor:.1e})={m_rel:.3e} > {tol:.1e} raw={k_raw:.3e}"
+
+
+def assert_close(x, ref, dtype, name, scale=1.0, sk=None, oracle=None, exact=None):
     """THE stated tolerance of this repo (DESIGN.md "Parity"): the reference's three bounds
     (max_abs 5e-3, mean_abs 2e-4, mean_rel 1e-2 for fp16; x8 for bf16), made magnitude-aware so they stay
     meaningful on the reference grid's degenerate shapes (e.g. sk = 1: dV sums 1024 N(0,1) terms,
@@ -72,10 +120,10 @@ def assert_close(x, ref, dtype, name, scale=1.0, sk=None):
       * the expectation is rounded to the output format first (round_like_output);
       * max_abs:  max(|d| - ulp_out * |ref|)        <= 5e-3   (one output ulp of slack per element)
       * mean_abs: mean|d| - ulp_out/2 * mean|ref|   <= 2e-4   (half an ulp on average)
-      * mean_rel: mean(|d| / max(|ref|, 1e-6, 0.01 * rms(ref))) <= 1e-2  -- elements below 1 % of the
-        tensor's RMS are measured against 1 % of the RMS instead of against (nearly) zero; skipped when
-        the expectation is identically ~0 (a single visible key makes dS = P (dP - D) vanish analytically
-        while any kernel leaves ~1e-7 of summation-order noise).
+      * mean_rel: the reference's RAW metric, see check_mean_rel (`oracle` = the C oracle's contract-mode result for this
+        tensor when the caller has it; `exact` = exact-arithmetic expectation for the relative metric when `ref` itself is the
+        oracle's result - small problems, where max_abs / mean_abs are measured against the reference algorithm with its
+        rounding points and mean_rel against exact math for kernel and oracle alike).
     For |values| <~ 1 (every non-degenerate case) these reduce to the reference's plain bounds.
     `sk` (keys per query, when the caller knows it): every case with sk >= 64 must ALSO meet the reference's PLAIN bounds
     (reference test_flash_attn.py:407-414: no ulp slack, no floor) against the expectation in the output format, wherever the
@@ -83,8 +131,7 @@ def assert_close(x, ref, dtype, name, scale=1.0, sk=None):
     rounding flip there already spends the bound) and mean_abs <= 2e-4 when mean|ref| <= 0.25 (the mean half-ulp of a tensor with
     mean |x| = 0.8 is 2e-4 by itself).  First GPU run with the unconditional form (profiles/r2_parity_margins_first_run.json):
     O and dQ met the plain bounds on every one of ~2400 cases; dK / dV exceeded them on 6 cases, all sq >> sk with GQA
-    (e.g. lq = 1002, lk = 99, 6 q-heads per kv-head: |dV| ~ 0.8-16), by exactly one output ulp.  The plain mean_rel
-    (|d| / max(|ref|, 1e-6), dominated by the few elements whose expectation is ~0) is recorded, not asserted.
+    (e.g. lq = 1002, lk = 99, 6 q-heads per kv-head: |dV| ~ 0.8-16), by exactly one output ulp.
     The worst raw metrics per test family go to MARGINS (-> gpurun_out/parity_margins.json).
     Returns the raw reference-style metrics for logging."""
     xa = np.asarray(x, dtype=np.float64)
@@ -107,10 +154,8 @@ def assert_close(x, ref, dtype, name, scale=1.0, sk=None):
     m_mean = float(diff.mean() - 0.5 * ulp * aref.mean())
     assert m_max <= tol["max_abs"] * scale, f"{name} max_abs(excess over 1 ulp)={m_max:.3e} > {tol['max_abs'] * scale:.3e} raw={raw}"
     assert m_mean <= tol["mean_abs"] * scale, f"{name} mean_abs(excess over ulp/2)={m_mean:.3e} > {tol['mean_abs'] * scale:.3e} raw={raw}"
-    if aref.max() >= 1e-4:
-        floor = max(REL_EPS, 0.01 * float(np.sqrt(np.mean(ref * ref))))
-        m_rel = float((diff / np.maximum(aref, floor)).mean())
-        assert m_rel <= tol["mean_rel"] * scale, f"{name} mean_rel(floor {floor:.1e})={m_rel:.3e} > {tol['mean_rel'] * scale:.3e} raw={raw}"
+    e = ref if exact is None else round_like_output(exact, dtype).astype(np.float64)
+    check_mean_rel(xa, e, dtype, name, scale, sk, oracle)
     return raw
 
 

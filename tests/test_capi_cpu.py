@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/flash_attn_gfx950.h but not exported"
-    assert L.fa_abi_version() == 3
+    assert L.fa_abi_version() == 4
     assert b"gfx950" in L.fa_build_info()
 
 
@@ -62,14 +62,52 @@ def test_host_validation_error_codes_without_gpu():
 
 
 def test_struct_layout_matches_header():
-    # 7 pointers + 8 int32 + 4 x 3 int64 + 2 int64 (ABI 2: total_q, total_k) ; 12 pointers + 8 int32 + 8 x 3 int64 + 2 int64
-    assert ctypes.sizeof(capi.FwdParams) == 7 * 8 + 8 * 4 + 4 * 24 + 16
-    # ABI 3: + workspace pointer + workspace_bytes at the end of the backward struct
-    assert ctypes.sizeof(capi.BwdParams) == 12 * 8 + 8 * 4 + 8 * 24 + 16 + 16
-    # the ABI 1 prefix is unchanged: the appended fields sit at the very end
-    assert capi.FwdParams.total_q.offset == 7 * 8 + 8 * 4 + 4 * 24 and capi.BwdParams.total_q.offset == 12 * 8 + 8 * 4 + 8 * 24
+    # ABI 4 header {struct_size, magic} + 7 pointers + 8 int32 + 4 x 3 int64 + 2 int64 (total_q, total_k);
+    # header + 12 pointers + 8 int32 + 8 x 3 int64 + 2 int64 + workspace pointer + workspace_bytes
+    assert ctypes.sizeof(capi.FwdParams) == 8 + 7 * 8 + 8 * 4 + 4 * 24 + 16
+    assert ctypes.sizeof(capi.BwdParams) == 8 + 12 * 8 + 8 * 4 + 8 * 24 + 16 + 16
+    assert capi.FwdParams.struct_size.offset == 0 and capi.FwdParams.magic.offset == 4 and capi.FwdParams.q.offset == 8
+    # the optional fields sit at the very end, in the order they were appended
+    assert capi.FwdParams.total_q.offset == 8 + 7 * 8 + 8 * 4 + 4 * 24 and capi.BwdParams.total_q.offset == 8 + 12 * 8 + 8 * 4 + 8 * 24
     assert capi.BwdParams.workspace.offset == capi.BwdParams.total_k.offset + 8
-    assert capi.lib().fa_abi_version() == 3
+    assert capi.lib().fa_abi_version() == 4
+    # the header's constant and the binding's agree
+    import re
+    with open(capi.HEADER_PATH) as f:
+        assert int(re.search(r"#define FA_PARAMS_MAGIC (0x[0-9A-Fa-f]+)u", f.read()).group(1), 16) == capi.FA_PARAMS_MAGIC
+
+
+def test_abi_header_guards_struct_size():
+    """ABI 4: a struct without the {struct_size, magic} header (what an ABI 1-3 caller would pass: its q pointer sits there), one
+    shorter than the mandatory part, or one longer than the library knows is FA_ERR_BAD_ABI, before anything is read past its end;
+    a struct that stops before the appended optional fields is accepted and those fields default to "not given"."""
+    L = capi.lib()
+    p = _bwd_params_host_only(4, 8192, 8192, 32, 1, 128, True)
+    full = capi.bwd_workspace_bytes(p)
+    assert full > 0
+    # (1) an ABI 3 caller: no header, first 8 bytes = a device pointer
+    p.struct_size, p.magic = 0x7F3A1000, 0x00007F12
+    assert L.fa_bwd_workspace_bytes(ctypes.byref(p)) == capi.FA_ERR_BAD_ABI and "ABI < 4" in capi.last_error()
+    assert L.fa_run_mha_bwd(ctypes.byref(p), None) == capi.FA_ERR_BAD_ABI
+    # (2) sizes outside [mandatory part, sizeof]
+    p.magic = capi.FA_PARAMS_MAGIC
+    for bad in (0, capi.BwdParams.total_q.offset - 8, ctypes.sizeof(capi.BwdParams) + 8):
+        p.struct_size = bad
+        assert L.fa_bwd_workspace_bytes(ctypes.byref(p)) == capi.FA_ERR_BAD_ABI, bad
+    # (3) a caller whose struct ends before `workspace` (an older ABI >= 4 header): accepted; the fields it does not have are never
+    # read - poison them to prove it
+    p.struct_size = capi.BwdParams.workspace.offset
+    p.workspace, p.workspace_bytes = 0xDEAD0001, -5
+    assert L.fa_bwd_workspace_bytes(ctypes.byref(p)) == full
+    # ... and one that ends before total_q / total_k: a packed batch then has no totals -> no split
+    v = _bwd_params_host_only(2, 1024, 1024, 8, 1, 128, True, total_k=1500, varlen=True)
+    assert capi.bwd_workspace_bytes(v) > 0
+    v.struct_size = capi.BwdParams.total_q.offset
+    assert capi.bwd_workspace_bytes(v) == 0
+    f = capi.FwdParams()
+    f.b, f.seqlen_q, f.seqlen_k, f.h, f.h_k, f.d, f.dtype = 1, 8, 8, 3, 2, 128, 0
+    f.magic = 0
+    assert L.fa_run_mha_fwd(ctypes.byref(f), None) == capi.FA_ERR_BAD_ABI
 
 
 def _bwd_params_host_only(b, sq, sk, h, hk, d, causal, total_k=0, varlen=False):
@@ -104,6 +142,22 @@ def test_dkdv_workspace_rule_host_arithmetic():
     assert W(2, 1024, 1024, 6, 1, 64, True) == 2 * plane(2, 1024, 1, 64)         # group of 6: 2 divides, 4 does not
     assert W(2, 1024, 1024, 8, 1, 128, True, varlen=True) == 0                   # packed tensors without total_k: no split
     assert W(2, 1024, 1024, 8, 1, 128, True, total_k=1500, varlen=True) == 8 * 2 * 1500 * 128 * 4
+    # uniform-length packed batches take the PLAIN grid (varlen_slot_count() == 0): they are sized like the dense equivalent, not
+    # split to the hilt (round-2 advisor finding: b8 x 8192 GQA 32/8 asked for 2 GiB, MQA h64 b16 for 8 GiB)
+    assert W(8, 8192, 8192, 32, 8, 128, False, total_k=8 * 8192, varlen=True) == W(8, 8192, 8192, 32, 8, 128, False) == 0
+    assert W(16, 8192, 8192, 64, 1, 128, True, total_k=16 * 8192, varlen=True) == W(16, 8192, 8192, 64, 1, 128, True) == 0
+    assert W(4, 8192, 8192, 32, 1, 128, True, total_k=4 * 8192, varlen=True) == W(4, 8192, 8192, 32, 1, 128, True)
+    # more sequences than the compact grid handles (kVarlenMaxBatch = 512): plain grid as well
+    assert W(600, 256, 256, 8, 1, 128, True, total_k=600 * 256, varlen=True) == W(600, 256, 256, 8, 1, 128, True) == 0
+    # the request is bounded by construction: it is only made while the grid is below 4 x 256 workgroups of 128 keys
+    for args in ((4, 8192, 8192, 32, 1, 128, True), (1, 2048, 2048, 32, 1, 128, False), (2, 1024, 1024, 6, 1, 64, True)):
+        assert W(*args) <= 2 * 2 * (4 * 256) * 128 * 128 * 4
+    # the `workspace` fields of the argument are ignored here: a stale / unaligned pointer or a negative size left in a reused struct
+    # does not turn a size query into an error (they ARE validated by the launches that use them)
     p = _bwd_params_host_only(1, 128, 128, 8, 1, 128, True)
-    p.workspace_bytes = -1
-    assert capi.lib().fa_bwd_workspace_bytes(ctypes.byref(p)) == capi.FA_ERR_BAD_SHAPE
+    want = capi.bwd_workspace_bytes(p)
+    p.workspace, p.workspace_bytes = 0x1003, -1
+    assert capi.lib().fa_bwd_workspace_bytes(ctypes.byref(p)) == want
+    assert capi.lib().fa_bwd_dkdv(ctypes.byref(p), None) == capi.FA_ERR_BAD_SHAPE
+    p.workspace_bytes = 64
+    assert capi.lib().fa_bwd_dkdv(ctypes.byref(p), None) == capi.FA_ERR_BAD_STRIDE

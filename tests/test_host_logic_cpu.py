@@ -9,7 +9,7 @@ def test_module_surface_matches_reference_exports():
     # reference csrc/flash_attn/flash_api.cpp:471-476 + README's flash_attn_func
     for name in ("fwd", "bwd", "varlen_fwd", "varlen_bwd", "flash_attn_func"):
         assert callable(getattr(F, name))
-    assert F.abi_version() == 3
+    assert F.abi_version() == 4
 
 
 def test_cpu_tensors_are_rejected_not_silently_computed():
