@@ -272,7 +272,7 @@ class PowerSampler:
         import threading
 
         self.period, self.samples, self._stop, self._thr = period_s, [], threading.Event(), None
-        self.power_path = self.sclk_path = None
+        self.power_path = self.sclk_path = self.cap_w = None
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
         # (one GPU per box in this pool; with several, rank r reads the r-th card that exposes a power sensor)
         cands = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
@@ -284,6 +284,7 @@ class PowerSampler:
                     break
             if os.path.exists(os.path.join(h, "freq1_input")):
                 self.sclk_path = os.path.join(h, "freq1_input")
+            self.cap_w = (self._read(os.path.join(h, "power1_cap")) or 0.0) / 1e6 or None
         self._threading = threading
 
     @staticmethod
@@ -317,7 +318,9 @@ class PowerSampler:
         inside = [x for x in self.samples if t0 <= x[0] <= t1]
         pw = [x[1] / 1e6 for x in inside if x[1] is not None]
         ck = [x[2] / 1e6 for x in inside if x[2] is not None]
-        out = {"region": what, "samples": len(inside), "sensor": self.power_path or self.sclk_path}
+        out = {"region": what, "samples": len(inside), "sensor": self.power_path or self.sclk_path, "power_cap_w": self.cap_w,
+               "note": "freq1_input is the clock the SMU reports (its target), not the delivered one: the effective clock under MFMA load "
+                       "comes from GRBM_GUI_ACTIVE / time in profiles/*shader_pmc_summary.json"}
         if pw:
             out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
         if ck:

@@ -23,9 +23,9 @@
 //     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312); with caller-provided fp32 scratch the group is
 //     split over workgroups when the grid would otherwise be small or causally unbalanced;
 //   * operands that never change inside a kernel's loop live in registers (Q / dO fragments in dQ, K and part of V in dK/dV).
+#include <stdlib.h>
 #include <type_traits>
-#include "fa_device.hpp"
-#include "fa_params.hpp"
+#include "fa_bwd_dkdv_common.hpp"
 
 namespace fa {
 
@@ -107,6 +107,21 @@ template <typename T, int D, bool CAUSAL>
 #define FA_KV_VREG(D) ((D) == 128 ? 2 : 0)
 #endif
 #define FA_KV_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+// dK/dV, D = 128: who issues the Q / dO tile DMA, and when.  Per-phase s_memtime stamps (tools/phase_timing_dkdv.py,
+// profiles/r3_dkdv_phase_timing.log) showed the two q-half groups badly out of balance: waves 0-3 (dispatched first = older = win every
+// arbitration) finish a tile ~1000 cycles before waves 4-7 and park at the barrier, while every wave pays 450-600 cycles at the top of
+// the iteration to issue its four 1-KiB DMA pieces with the matrix pipe idle.  1: waves 0-3 issue ALL pieces of tile t+2 at the END of
+// their tile t, in the time they would otherwise spend waiting; the rings are 3 deep for that (the third slot is the K tile's home,
+// free once K sits in registers).  0: every wave issues its share of tile t+1 at the top of iteration t (2-deep rings; D = 64).
+#ifndef FA_KV_TAIL_DMA
+#define FA_KV_TAIL_DMA(D) 0
+#endif
+#ifndef FA_KV_PF2
+#define FA_KV_PF2 3             // dV / dK phase: transposed fragments in flight
+#endif
+#ifndef FA_KV_STAGGER_DMA
+#define FA_KV_STAGGER_DMA 1
+#endif
 __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
     constexpr int TILEB = kDqBlockN * ROWB;
@@ -368,10 +383,17 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
 // tiles arrive by LDS-DMA.
 // LDS: K[128 keys] | V[128 keys] | Q ring[2] | dO ring[2] | stats ring[2]  = 129 KiB.
 // =============================================================================================
-constexpr int kKvThreads = 512;
-constexpr int kKvBlockN = 128;   // keys per workgroup (32 per key block, 4 key blocks)
-constexpr int kKvBlockM = 64;    // query rows per staged tile (two 32-row halves)
+// (workgroup shape kKvThreads / kKvBlockN / kKvBlockM and the epilogue: fa_bwd_dkdv_common.hpp.  D = 128 launches go to the two-group
+// ping-pong kernel in fa_bwd_dkdv_pp.hip - same arithmetic, bit-identical results; this lock-step kernel serves D = 64, where two
+// workgroups per CU already interleave four waves per SIMD, and stays instantiated at D = 128 as the A/B baseline: FA_DKDV_LOCKSTEP=1.)
 
+// -DFA_KV_TIMING (development aid, tools/phase_timing_dkdv.py): per-wave s_memtime stamps at the phase edges of the tile loop, summed per
+// phase and left in p.ws[(block * 8 + wave) * 8 + phase] (the caller passes a workspace; MHA launches never use it otherwise)
+#ifdef FA_KV_TIMING
+#define FA_KV_STAMP(i) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define FA_KV_STAMP(i) do { } while (0)
+#endif
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_kernel(const BwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
@@ -379,7 +401,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     constexpr int TILEB = kKvBlockM * ROWB;                 // one Q (or dO) tile
     constexpr int STATB = 2 * kKvBlockM * 4;                // lse2 + dsum of one tile
     constexpr int OFF_V = KVB, OFF_Q = 2 * KVB, OFF_DO = 2 * KVB + 2 * TILEB, OFF_STAT = 2 * KVB + 4 * TILEB;
-    __shared__ __attribute__((aligned(16))) char smem_raw[OFF_STAT + 2 * STATB];   // the only LDS object
+    constexpr bool kTail = FA_KV_TAIL_DMA(D);
+    constexpr int RING = kTail ? 3 : 2;
+    static_assert(!kTail || 2 * TILEB <= KVB, "the third ring slots live in the K tile's region");
+    __shared__ __attribute__((aligned(16))) char smem_raw[OFF_STAT + RING * STATB];   // the only LDS object
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
     FA_LDS char* ktile = smem;
     FA_LDS char* vtile = smem + OFF_V;
@@ -417,12 +442,9 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     const T* v_base = uniform_ptr((const T*)p.v_ptr + v_boff + (k_row0 + n0) * p.v.row + (int64_t)head_k * p.v.head);
     T* dk_base = uniform_ptr((T*)p.dk_ptr + dk_boff + (k_row0 + n0) * p.dk.row + (int64_t)head_k * p.dk.head);
     T* dv_base = uniform_ptr((T*)p.dv_ptr + dv_boff + (k_row0 + n0) * p.dv.row + (int64_t)head_k * p.dv.head);
-    const uint32_t k_rowb = (uint32_t)(p.k.row * 2), v_rowb = (uint32_t)(p.v.row * 2), dk_rowb = (uint32_t)(p.dk.row * 2),
-                   dv_rowb = (uint32_t)(p.dv.row * 2), q_rowb = (uint32_t)(p.q.row * 2), do_rowb = (uint32_t)(p.dout.row * 2);
+    const uint32_t k_rowb = (uint32_t)(p.k.row * 2), v_rowb = (uint32_t)(p.v.row * 2), q_rowb = (uint32_t)(p.q.row * 2), do_rowb = (uint32_t)(p.dout.row * 2);
     const srd_t k_srd = make_srd(k_base, (uint32_t)(keys_here - 1) * k_rowb + ROWB);
     const srd_t v_srd = make_srd(v_base, (uint32_t)(keys_here - 1) * v_rowb + ROWB);
-    const rsrc_t dk_rs = make_rsrc(dk_base, (uint32_t)(keys_here - 1) * dk_rowb + ROWB);
-    const rsrc_t dv_rs = make_rsrc(dv_base, (uint32_t)(keys_here - 1) * dv_rowb + ROWB);
 
     // Q-tile range: key j is visible to query i iff i >= j - delta
     const int n_q_tiles = (sq + kKvBlockM - 1) / kKvBlockM;
@@ -443,12 +465,17 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         return (uint32_t)row * rowb + lds_tile_logical_slot<D>(row, phys) * 16;
     };
     const uint32_t lds0 = lds_addr(smem);
+    // kTail: wave w < 4 moves pieces w, w + 4, w + 8, w + 12 of BOTH tensors; pieces 4 apart are 16 rows apart and share their swizzle,
+    // so one per-lane offset per tensor is enough and the rest goes into the instruction's scalar offset
     uint32_t q_src[PPW_Q], do_src[PPW_Q];                  // per-lane source offsets of this wave's Q/dO pieces
 #pragma unroll
     for (int i = 0; i < PPW_Q; ++i) {
-        q_src[i] = piece_src(wave * PPW_Q + i, q_rowb);
-        do_src[i] = piece_src(wave * PPW_Q + i, do_rowb);
+        q_src[i] = piece_src(kTail ? (wave & 3) : wave * PPW_Q + i, q_rowb);
+        do_src[i] = piece_src(kTail ? (wave & 3) : wave * PPW_Q + i, do_rowb);
     }
+    // ring slot -> LDS offset of the Q / dO tile (kTail: slot 2 = the K tile's region)
+    auto q_slot = [&](int s_) { return kTail && s_ == 2 ? 0 : OFF_Q + s_ * TILEB; };
+    auto do_slot = [&](int s_) { return kTail && s_ == 2 ? TILEB : OFF_DO + s_ * TILEB; };
 
     // rows read as MFMA operands with 8 contiguous d per lane (row reads): row l31 (+32*block), slot 2*ks+hi
     uint32_t row_rd[KS];
@@ -471,45 +498,59 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[db][r] = 0.f; dvacc[db][r] = 0.f; }
 
-    // iteration -> (query head, first row of the q tile)
-    auto tile_coords = [&](int it, int& hq, int& m0) {
-        const int g = it / tiles_per_head;
-        hq = head_k * p.h_ratio + split * heads_here + g;
-        m0 = (qt_begin + (it - g * tiles_per_head)) * kKvBlockM;
+    // The Q / dO / statistics streams of ONE query head are addressed through descriptors that are rebuilt only when the stream moves on
+    // to the next head of the group; inside a head a tile costs one scalar multiply and one VALU add per DMA piece.  (Until round 3
+    // the descriptors were rebuilt for every tile: ~110 SALU instructions at the top of every iteration, 600-1000 cycles per tile with
+    // the matrix pipe idle - both waves of a SIMD do it at the same time; tools/phase_timing_dkdv.py, profiles/r3_dkdv_phase_timing.log.)
+    const int head_first = head_k * p.h_ratio + split * heads_here;
+    srd_t q_srd = make_srd(nullptr, 0), do_srd = make_srd(nullptr, 0);
+    rsrc_t st_rs = make_rsrc(nullptr, 0);
+    auto set_head = [&](int hq) {
+        const T* qb = uniform_ptr((const T*)p.q_ptr + q_boff + q_row0 * p.q.row + (int64_t)hq * p.q.head);
+        const T* dob = uniform_ptr((const T*)p.do_ptr + do_boff + q_row0 * p.dout.row + (int64_t)hq * p.dout.head);
+        q_srd = make_srd(qb, sq > 0 ? (uint32_t)(sq - 1) * q_rowb + ROWB : 0u);          // rows past the end of the sequence read zeros
+        do_srd = make_srd(dob, sq > 0 ? (uint32_t)(sq - 1) * do_rowb + ROWB : 0u);
+        // the 64 LSE / D values of a tile go through ONE register of waves 0 / 1 (other waves: zero-record descriptor, no access)
+        const float* sb = uniform_ptr((wave == 0 ? p.lse_ptr : p.dsum_ptr) + ((int64_t)batch * p.h + hq) * p.lse_row_stride);
+        st_rs = make_rsrc(sb, wave < 2 ? (uint32_t)sq * 4u : 0u);
     };
-    // Q/dO tile `it` -> ring slot buf by LDS-DMA issued from inline asm: nothing returns to a VGPR, hipcc has no reason to wait.
-    auto issue_tile = [&](int it, int buf) {
-        int hq, m0;
-        tile_coords(it, hq, m0);
-        const int rows = min(kKvBlockM, sq - m0);
-        const T* qb = uniform_ptr((const T*)p.q_ptr + q_boff + (q_row0 + m0) * p.q.row + (int64_t)hq * p.q.head);
-        const T* dob = uniform_ptr((const T*)p.do_ptr + do_boff + (q_row0 + m0) * p.dout.row + (int64_t)hq * p.dout.head);
-        const srd_t q_srd = make_srd(qb, (uint32_t)(rows - 1) * q_rowb + ROWB);
-        const srd_t do_srd = make_srd(dob, (uint32_t)(rows - 1) * do_rowb + ROWB);
+    // prefetch cursor: (query head, tile inside the head) of the next tile to request
+    int pf_head = head_first, pf_tile = 0;
+    auto pf_m0 = [&]() { return (qt_begin + pf_tile) * kKvBlockM; };
+    auto pf_advance = [&]() {
+        if (++pf_tile == tiles_per_head) { pf_tile = 0; ++pf_head; if (pf_head < head_first + heads_here) set_head(pf_head); }
+    };
+    // Q/dO tile at the cursor -> ring slot buf by LDS-DMA issued from inline asm: nothing returns to a VGPR, hipcc has no reason to wait.
+    auto issue_tile = [&](int buf) {
+        const uint32_t m0 = (uint32_t)pf_m0();
+        if constexpr (kTail) {                              // (waves 0-3 only: the caller checks)
+            constexpr int NP = kKvBlockM * SLOTS / 64 / 4;  // pieces per wave and tensor (4 at D = 128)
 #pragma unroll
-        for (int i = 0; i < PPW_Q; ++i) {
-            const int piece = wave * PPW_Q + i;
-            dma16_to_lds_hidden(q_srd, q_src[i], lds0 + OFF_Q + buf * TILEB + piece * 1024);
-            dma16_to_lds_hidden(do_srd, do_src[i], lds0 + OFF_DO + buf * TILEB + piece * 1024);
+            for (int i = 0; i < NP; ++i) {
+                const int piece = wave + 4 * i;
+                dma16_to_lds_hidden_soff(q_srd, q_src[0], (m0 + 16u * i) * q_rowb, lds0 + q_slot(buf) + piece * 1024);
+                dma16_to_lds_hidden_soff(do_srd, do_src[0], (m0 + 16u * i) * do_rowb, lds0 + do_slot(buf) + piece * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPW_Q; ++i) {
+                const int piece = wave * PPW_Q + i;
+                dma16_to_lds_hidden(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
+                dma16_to_lds_hidden(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
+            }
         }
     };
-    // The 64 LSE / D values of a tile go through ONE register of waves 0 / 1: loaded when the tile's DMA is issued, transformed
-    // (-LSE*log2e, -D) and written to the stats slot at the END of the same iteration, in front of the vmcnt(0) that is there anyway.
-    // The consumers then need no per-element multiply / subtract: exp2(fma(s, c, nl)) and a dP chain that starts from -D (16 VALU
-    // fewer per wave-tile each).  The load is unconditional and its register is consumed on every path.  History: in round 1 the
-    // statistics went through a register under an exec-masked branch and hipcc answered with `s_waitcnt vmcnt(0)` at the top of
-    // every iteration - a write-after-write guard for the paths that skipped the branch - right behind the DMA issue, exposing the
-    // L2 / HBM latency of the NEXT tile in front of the MFMAs of the current one (58 % of wave cycles parked, 35 % MFMA busy);
-    // raw LSE / D by 4-byte LDS-DMA fixed that (16.6 -> 14.2 ms backward at C4), this form keeps the fix and drops the VALU.
+    // Statistics of the tile at the cursor: loaded when the tile's DMA is issued, transformed (-LSE*log2e, -D) and written to the stats
+    // slot at the END of the same iteration, in front of the vmcnt(0) that is there anyway.  The consumers then need no per-element
+    // multiply / subtract: exp2(fma(s, c, nl)) and a dP chain that starts from -D (16 VALU fewer per wave-tile each).  The load is
+    // unconditional and its register is consumed on every path.  History: in round 1 the statistics went through a register under an
+    // exec-masked branch and hipcc answered with `s_waitcnt vmcnt(0)` at the top of every iteration - a write-after-write guard for
+    // the paths that skipped the branch - right behind the DMA issue, exposing the L2 / HBM latency of the NEXT tile in front of the
+    // MFMAs of the current one (58 % of wave cycles parked, 35 % MFMA busy).
     const float st_mult = wave == 0 ? -kLog2e : -1.0f;
-    auto load_stat = [&](int it, bool valid) -> float {     // every wave, every iteration (an invalid request is a zero-record SRD: no access)
-        int hq, m0;
-        tile_coords(it, hq, m0);
-        const int rows = (valid && wave < 2) ? min(kKvBlockM, sq - m0) : 0;
-        const int64_t so = ((int64_t)batch * p.h + hq) * p.lse_row_stride + m0;
-        const float* sb = uniform_ptr((wave == 0 ? p.lse_ptr : p.dsum_ptr) + so);
-        const rsrc_t rs = make_rsrc(sb, (uint32_t)rows * 4u);
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)lane * 4u, 0, 0));
+    auto load_stat = [&](bool valid) -> float {     // every wave, every iteration; !valid: an offset past every descriptor's range (returns 0)
+        const uint32_t off = valid ? ((uint32_t)pf_m0() + (uint32_t)lane) * 4u : 0xfffffff0u;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(st_rs, off, 0, 0));
     };
     auto store_stat = [&](float x, int buf) {
         *(FA_LDS float*)(stat + buf * STATB + wave * (kKvBlockM * 4) + lane * 4) = x * st_mult;
@@ -522,8 +563,12 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         dma16_to_lds_hidden(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
         dma16_to_lds_hidden(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
     }
-    if (n_iters > 0) issue_tile(0, 0);
-    if (n_iters > 0 && wave < 2) store_stat(load_stat(0, true), 0);
+    if (n_iters > 0) {
+        set_head(pf_head);
+        if (!kTail || qh == 0) issue_tile(0);
+        if (wave < 2) store_stat(load_stat(true), 0);
+        pf_advance();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -537,16 +582,40 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
     for (int ks = 0; ks < VREG; ++ks) vreg[ks] = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
 
+    float st_tail = 0.f;                                    // kTail: statistics of the tile in flight (waves 0 / 1)
+    if constexpr (kTail) {
+        // K is in registers everywhere before anything lands in its region: the reads have returned (the empty asm pins them), then a barrier
+#pragma unroll
+        for (int ks = 0; ks < KREG; ++ks) asm volatile("" : "+v"(kreg[ks < KREG ? ks : 0]));
+        __syncthreads();
+        const bool more = n_iters > 1;                      // tile 1 -> slot 1, awaited at the end of iteration 0
+        if (qh == 0 && more) issue_tile(1);
+        st_tail = load_stat(more);
+        if (more) pf_advance();
+    }
+#ifdef FA_KV_TIMING
+    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef FA_ABL_KV_PP     // timing-only ablation (WRONG results: the 2-deep ring is not safe under the offset): q-half groups half an iteration apart
+    if (qh == 1) __syncthreads();
+#endif
+    int cur_tile = 0, ring_slot = 0;                        // tile-in-head index / ring slot (kTail) of the tile being computed
     for (int it = 0; it < n_iters; ++it) {
-        int hq, m0;
-        tile_coords(it, hq, m0);
-        const int buf = it & 1;
-        FA_LDS char* qbuf = smem + OFF_Q + buf * TILEB;
-        FA_LDS char* dobuf = smem + OFF_DO + buf * TILEB;
+        const int m0 = (qt_begin + cur_tile) * kKvBlockM;
+        if (++cur_tile == tiles_per_head) cur_tile = 0;
+        const int buf = kTail ? ring_slot : (it & 1);
+        FA_LDS char* qbuf = smem + q_slot(buf);
+        FA_LDS char* dobuf = smem + do_slot(buf);
         FA_LDS char* sbuf = stat + buf * STATB;
         const bool more = (it + 1 < n_iters);
-        if (more) issue_tile(it + 1, buf ^ 1);             // ring slot buf^1 was last read in iteration it-1
-        const float st_next = load_stat(it + 1, more);
+        FA_KV_STAMP(5);                                     // (loop edge + barrier exit)
+        float st_next = 0.f;
+        if constexpr (!kTail) {
+            if (more && (!FA_KV_STAGGER_DMA || qh == 0)) issue_tile(buf ^ 1);      // ring slot buf^1 was last read in iteration it-1
+            st_next = load_stat(more);
+            if (!FA_KV_STAGGER_DMA && more) pf_advance();
+        }
+        FA_KV_STAMP(0);                                     // DMA issue
 
         // wave-level causal skip: all 32 rows of this wave's half are above the diagonal for all its 32 keys
         const int mh = m0 + 32 * qh;                       // first query row of this wave's half
@@ -586,6 +655,14 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 sacc = LP<T>::mfma(qa, kf, sacc);                   // S = Q K^T  (rows = queries, lane = key)
                 dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
             }
+            FA_KV_STAMP(1);                                 // S / dP MFMAs
+            if constexpr (!kTail && FA_KV_STAGGER_DMA) {    // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
+                if (more && qh == 1) issue_tile(buf ^ 1);
+                if (more) pf_advance();
+            }
+#ifdef FA_ABL_KV_PP
+            __syncthreads();
+#endif
             f32x16 pacc;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -609,7 +686,8 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 pfr[half] = pack_c_half<T>(pacc, half);             // P rounded (flash_bwd_kernel.h:1359)
                 dsfr[half] = pack_c_half<T>(sacc, half);            // dS rounded (:1360)
             }
-            constexpr int NST = 4 * DB, PF = 3;                     // step j = (half, db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
+            FA_KV_STAMP(2);                                 // exp / mask / dS / pack
+            constexpr int NST = 4 * DB, PF = FA_KV_PF2;                  // step j = (half, db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
             auto rd_frag = [&](int j) {
                 const int half = j / (2 * DB), db = (j >> 1) % DB, ts = 2 * qh + half;
                 FA_LDS char* src = (j & 1) ? qbuf : dobuf;
@@ -630,96 +708,42 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (more && wave < 2) store_stat(st_next, buf ^ 1);
-        asm volatile("" :: "v"(st_next));                   // consumed on every path: hipcc never has to guard the register at the loop top
-        // (timing-only ablations, profiles/r2_bwd_dkdv_lds_ab.log: without this wait -0.2 %, without wait AND barrier -5..-6 %)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
+        FA_KV_STAMP(3);                                     // dV / dK MFMAs
+        if constexpr (kTail) {
+            // tile it+1 (requested one iteration ago) has landed and its statistics are in st_tail; then waves 0-3 request tile it+2
+            // into the slot of tile it-1 - every wave left that tile behind at the previous barrier - and go to the barrier
+            const int slot1 = ring_slot == 2 ? 0 : ring_slot + 1, slot2 = ring_slot == 0 ? 2 : ring_slot - 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FA_KV_STAMP(4);
+            if (more && wave < 2) store_stat(st_tail, slot1);
+            asm volatile("" :: "v"(st_tail));
+            const bool more2 = it + 2 < n_iters;
+            if (qh == 0 && more2) issue_tile(slot2);
+            st_tail = load_stat(more2);
+            if (more2) pf_advance();
+            ring_slot = slot1;
+        } else {
+            if (more && wave < 2) store_stat(st_next, buf ^ 1);
+            asm volatile("" :: "v"(st_next));               // consumed on every path: hipcc never has to guard the register at the loop top
+            // (timing-only ablations, profiles/r2_bwd_dkdv_lds_ab.log: without this wait -0.2 %, without wait AND barrier -5..-6 %)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
+            FA_KV_STAMP(4);                                 // vmcnt wait
+        }
         __syncthreads();
     }
+#ifdef FA_KV_TIMING
+    if (p.ws != nullptr && lane == 0) {
+        float* out = p.ws + ((int64_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 6; ++i) out[i] = (float)tacc[i];
+        out[6] = (float)n_iters;
+    }
+#endif
 
-    // ---- epilogue -------------------------------------------------------------------------------------
-    // The accumulators were last written by MFMAs issued from inline asm, which the hazard recogniser does not see:
-    // an 8-pass XDL write needs 11+ wait states before a VALU (v_accvgpr_read) may read it.  Pad explicitly, and tie
-    // every accumulator to a statement after the pad so no read can be scheduled above it.
-    asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < DB; ++db) { asm volatile("" : "+a"(dkacc[db])); asm volatile("" : "+a"(dvacc[db])); }
-    // (the loop's last barrier has passed: K/V tiles, rings and stats are dead, LDS is scratch)
-    // 1) the qh = 1 waves hand their partial sums to their qh = 0 partner through LDS (fp32,
-    //    [key block][register][lane], conflict-free); 2) the partner adds, applies the softmax
-    //    scale to dK (flash_bwd_kernel.h:1652-1654), rounds and writes the staged 128-key tile;
-    //    3) all threads store whole rows.  dK and dV take turns in the same scratch.
-    constexpr int XR = DB * 16;                                                // accumulator registers per lane and tensor
-    FA_LDS float* xch = (FA_LDS float*)smem;                                   // 4 key blocks x XR x 64 lanes floats (64 KiB at d=128)
-    FA_LDS char* out_t = smem + 4 * XR * 64 * 4;                               // staged output tile (32 KiB at d=128)
-    static_assert(4 * XR * 64 * 4 + kKvBlockN * ROWB <= OFF_STAT, "epilogue scratch must fit");
-    constexpr int O_CHUNKS = (kKvBlockN * SLOTS) / kKvThreads;
-    auto reduce_and_store = [&](f32x16 (&acc)[DB], float mult, rsrc_t rs, uint32_t rowb) {
-        if (qh == 1) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xch[(kb * XR + db * 16 + r) * 64 + lane] = acc[db][r];
-        }
-        __syncthreads();
-        if (qh == 0) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v4[e] = (acc[db][4 * g4 + e] + xch[(kb * XR + db * 16 + 4 * g4 + e) * 64 + lane]) * mult;
-                    u32x2 w;
-                    w.x = LP<T>::pack2(v4[0], v4[1]);
-                    w.y = LP<T>::pack2(v4[2], v4[3]);
-                    lds_write8(out_t, lds_tile_off<D>(key_row, 4 * db + g4) + 8 * hi, w);
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < O_CHUNKS; ++i) {
-            const int chunk = tid + i * kKvThreads, row = chunk / SLOTS, slot = chunk % SLOTS;
-            buf_store16(rs, (uint32_t)row * rowb + slot * 16, lds_read16(out_t, lds_tile_off<D>(row, slot)));
-        }
-        __syncthreads();                                                       // scratch is reused by the next tensor
-    };
-    if (p.n_split == 1) {
-        reduce_and_store(dkacc, p.scale, dk_rs, dk_rowb);
-        reduce_and_store(dvacc, 1.0f, dv_rs, dv_rowb);
-        return;
-    }
-    // split group: the two q-halves still meet through LDS, the sum leaves as fp32 (unscaled) into this split's plane of the
-    // workspace; 16 bytes per lane per store, a key's row is 4 * D bytes
-    const int64_t plane = p.ws_rows * p.h_k * D;                                            // floats per (tensor, split)
-    const int64_t row0 = (p.cu_seqlens_k != nullptr ? k_row0 : (int64_t)batch * p.seqlen_k) + n0;
-    auto reduce_to_workspace = [&](f32x16 (&acc)[DB], int tensor) {
-        if (qh == 1) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xch[(kb * XR + db * 16 + r) * 64 + lane] = acc[db][r];
-        }
-        __syncthreads();
-        if (qh == 0) {
-            float* base = uniform_ptr(p.ws + ((int64_t)tensor * p.n_split + split) * plane + (row0 * p.h_k + head_k) * D);
-            const rsrc_t rs = make_rsrc(base, (uint32_t)(keys_here - 1) * (uint32_t)(p.h_k * D * 4) + D * 4);
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    u32x4 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        w[e] = __builtin_bit_cast(uint32_t, acc[db][4 * g4 + e] + xch[(kb * XR + db * 16 + 4 * g4 + e) * 64 + lane]);
-                    buf_store16(rs, (uint32_t)key_row * (uint32_t)(p.h_k * D * 4) + (32 * db + 8 * g4 + 4 * hi) * 4, w);   // rows >= keys_here fall outside the SRD
-                }
-        }
-        __syncthreads();                                                       // scratch is reused by the next tensor
-    };
-    reduce_to_workspace(dkacc, 0);
-    reduce_to_workspace(dvacc, 1);
+#ifdef FA_ABL_KV_PP
+    if (qh == 0) __syncthreads();
+#endif
+    // ---- epilogue (fa_bwd_dkdv_common.hpp): the loop's last barrier has passed, K/V tiles, rings and stats are dead, LDS is scratch ----
+    dkdv_epilogue<T, D, OFF_STAT>(p, smem, dkacc, dvacc, batch, head_k, split, k_row0, n0, keys_here, dk_base, dv_base);
 }
 
 // Sum of the n_split fp32 partial dK / dV planes (fixed order: deterministic), softmax scale on dK (flash_bwd_kernel.h:1652-1654),
@@ -773,13 +797,26 @@ static hipError_t launch_dq_t(const BwdKernelParams& kp, hipStream_t s) {
     else hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, false>), dim3(grid), dim3(kDqThreads), 0, s, kp);
     return hipGetLastError();
 }
+// FA_DKDV_LOCKSTEP=1 in the environment (read once): D = 128 keeps the lock-step kernel - the in-process A/B switch of tools/ab_env.py
+static bool dkdv_lockstep_forced() {
+#ifdef FA_DKDV_FORCE_LOCKSTEP          // tools/build_variant.py: the A/B arm that keeps the lock-step kernel at D = 128
+    return true;
+#endif
+    static const bool v = [] { const char* e = getenv("FA_DKDV_LOCKSTEP"); return e != nullptr && e[0] == '1'; }();
+    return v;
+}
 template <typename T, int D>
 static hipError_t launch_dkdv_t(const BwdKernelParams& kp, hipStream_t s) {
     const uint32_t grid = (kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h_k : kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k) * (uint32_t)kp.n_split;
     if (grid == 0) return hipSuccess;
-    if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-    else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (D == 128 && !dkdv_lockstep_forced()) {
+        e = launch_dkdv_pp(kp, std::is_same<T, _Float16>::value ? 0 : 1, grid, s);
+    } else {
+        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess || kp.n_split == 1) return e;
     const int64_t items = kp.ws_rows * kp.h_k * (D / 8);
     hipLaunchKernelGGL((fa_bwd_sum_splits_kernel<T, D>), dim3((uint32_t)((items + kSumThreads - 1) / kSumThreads)), dim3(kSumThreads), 0, s, kp);

@@ -17,13 +17,21 @@ _KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", r"ScratchSize \[bytes/lane\]": "scr
 
 
 def _loops(body):
-    """(label, text) of every backward-branch region: label ... branch back to that label"""
+    """(label, text) of every loop, from the compiler's own block annotations: the block it marks `; =>This [Inner] Loop Header` plus
+    every block marked `in Loop: Header=<that label>` (labelled blocks and fall-through `; %bb.N:` blocks alike), wherever the block
+    placement put them - a rotated loop's body sits BEFORE its header in the text, and a label followed somewhere by a branch to it
+    may just be a forward branch from a block placed later (that once made a kernel's accumulator zero-initialisation look like 128
+    accumulator moves inside a loop)."""
+    starts = [(m.start(), m.group(0)) for m in re.finditer(r"^(?:\.LBB\d+_\d+:|; %bb\.\d+:)[^\n]*$", body, re.M)]
+    blocks = [(line, body[a:(starts[i + 1][0] if i + 1 < len(starts) else len(body))]) for i, (a, line) in enumerate(starts)]
     out = []
-    for m in re.finditer(r"^(\.LBB\d+_\d+):", body, re.M):
-        lab, a = m.group(1), m.end()
-        ends = [b.end() for b in re.finditer(r"s_c?branch\w* " + re.escape(lab) + r"\b", body[a:])]
-        if ends:
-            out.append((lab, body[a:a + max(ends)]))
+    for line, _ in blocks:
+        m = re.match(r"\.(LBB\d+_\d+):.*Loop Header", line)
+        if not m:
+            continue
+        hdr = m.group(1)[1:]                                   # "BB9_30"
+        text = "".join(t for l, t in blocks if l.startswith("." + "L" + hdr + ":") or re.search(r"in Loop: Header=" + hdr + r"\b", l))
+        out.append(("." + "L" + hdr, text))
     return out
 
 

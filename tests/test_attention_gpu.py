@@ -79,7 +79,7 @@ def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype):
     dq_ref, dk_ref, dv_ref = A.attn_bwd(t["q"], t["k"], t["v"], o_ref, lse_ref, t["dout"], causal=causal, round_mode=mode)
     # mean_rel: kernel and oracle are both measured against exact fp32 math (tests/_util.py:check_mean_rel)
     tq, tk, tv, tdo = (U.to_device(t[n], dtype, gpu) for n in ("q", "k", "v", "dout"))
-    xo, _, xdq, xdk, xdv = (x.cpu().numpy() for x in U.torch_attention_ref(tq, tk, tv, tdo, causal))
+    xo, _, xdq, xdk, xdv = (x.numpy() for x in U.torch_attention_ref(tq, tk, tv, tdo, causal, device="cpu", dtype=torch.float64))
     U.assert_close(o, o_ref, dtype, "O", sk=sk, oracle=o_ref, exact=xo)
     assert np.abs(lse - lse_ref).max() <= U.LSE_TOL
     U.assert_close(dq, dq_ref, dtype, "dQ", sk=sk, oracle=dq_ref, exact=xdq)
@@ -128,7 +128,7 @@ def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, caus
             dq_n, dk_n, dv_n = A.attn_bwd(n(q), n(k), n(v), o_n, lse_n, n(do), causal=causal, round_mode=A.ROUND_FP16)
             o_ref, lse_ref, dq_ref, dk_ref, dv_ref = (torch.from_numpy(x) for x in (o_n, lse_n, dq_n, dk_n, dv_n))
             # mean_rel is measured against exact math for kernel and oracle alike (tests/_util.py:check_mean_rel, rule "oracle")
-            xo, _, xdq, xdk, xdv = U.torch_attention_ref(q, k, v, do, causal)
+            xo, _, xdq, xdk, xdv = U.torch_attention_ref(q, k, v, do, causal, device="cpu", dtype=torch.float64)
             orc = dict(O=(o_n, xo), dQ=(dq_n, xdq), dK=(dk_n, xdk), dV=(dv_n, xdv))
         else:
             o_ref, lse_ref, dq_ref, dk_ref, dv_ref = U.torch_attention_ref(q, k, v, do, causal)
@@ -170,10 +170,19 @@ def test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, d, causal):
             qs, ks = slice(cu_q[i], cu_q[i + 1]), slice(cu_k[i], cu_k[i + 1])
             o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q[qs][None], k[ks][None], v[ks][None], do[qs][None], causal)
             tag = f"seq{i} lq={lq[i]} lk={lk[i]}"
-            U.assert_close(o[qs].float().cpu().numpy(), o_r[0].cpu().numpy(), "fp16", "O " + tag, sk=int(lk[i]))
-            U.assert_close(dq[qs].float().cpu().numpy(), dq_r[0].cpu().numpy(), "fp16", "dQ " + tag, sk=int(lk[i]))
-            U.assert_close(dk[ks].float().cpu().numpy(), dk_r[0].cpu().numpy(), "fp16", "dK " + tag, sk=int(lk[i]))
-            U.assert_close(dv[ks].float().cpu().numpy(), dv_r[0].cpu().numpy(), "fp16", "dV " + tag, sk=int(lk[i]))
+            orc = {}
+            if lk[i] < U.PLAIN_SK_MIN:     # few keys: the relative metric is bounded by the C oracle's own error (tests/_util.py:check_mean_rel)
+                from oracle import attn_oracle as A
+
+                n = lambda t: t.float().cpu().numpy()
+                oo, ol = A.attn_fwd(n(q[qs][None]), n(k[ks][None]), n(v[ks][None]), causal=causal)
+                odq, odk, odv = A.attn_bwd(n(q[qs][None]), n(k[ks][None]), n(v[ks][None]), oo, ol, n(do[qs][None]), causal=causal)
+                orc = dict(O=oo[0], dQ=odq[0], dK=odk[0], dV=odv[0])
+            ex = lambda t: dict(oracle=orc[t]) if orc else {}
+            U.assert_close(o[qs].float().cpu().numpy(), o_r[0].cpu().numpy(), "fp16", "O " + tag, sk=int(lk[i]), **ex("O"))
+            U.assert_close(dq[qs].float().cpu().numpy(), dq_r[0].cpu().numpy(), "fp16", "dQ " + tag, sk=int(lk[i]), **ex("dQ"))
+            U.assert_close(dk[ks].float().cpu().numpy(), dk_r[0].cpu().numpy(), "fp16", "dK " + tag, sk=int(lk[i]), **ex("dK"))
+            U.assert_close(dv[ks].float().cpu().numpy(), dv_r[0].cpu().numpy(), "fp16", "dV " + tag, sk=int(lk[i]), **ex("dV"))
             assert (lse[i, :, : lq[i]] - lse_r[0]).abs().max().item() <= U.LSE_TOL, "LSE " + tag
             assert (lse[i, :, lq[i]:] == 0).all(), "padded LSE must stay zero"
 

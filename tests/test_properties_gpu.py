@@ -398,10 +398,18 @@ def test_running_max_rising_along_the_key_axis(gpu, d, dtype, ramp):
         o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, causal)
         assert torch.isfinite(o).all() and torch.isfinite(lse).all()
         assert ((lse - lse_r).abs() / lse_r.abs().clamp_min(1.0)).max().item() <= 1e-4
-        U.assert_close(o.float().cpu().numpy(), o_r.cpu().numpy(), dtype, f"O ramp {ramp}", scale=2.0)
-        for name, x, r in (("dQ", dq, dq_r), ("dK", dk, dk_r), ("dV", dv, dv_r)):
+        # a steep ramp leaves a handful of effective keys per row: the relative metric is bounded by what the reference ALGORITHM
+        # (C oracle, contract mode) itself achieves against the same fp32 expectation (tests/_util.py:check_mean_rel)
+        from oracle import attn_oracle as A
+
+        mode = A.ROUND_FP16 if dtype == "fp16" else A.ROUND_BF16
+        n = lambda t: t.float().cpu().numpy()
+        oo, ol = A.attn_fwd(n(q), n(k), n(v), causal=causal, round_mode=mode)
+        odq, odk, odv = A.attn_bwd(n(q), n(k), n(v), oo, ol, n(do), causal=causal, round_mode=mode)
+        U.assert_close(o.float().cpu().numpy(), o_r.cpu().numpy(), dtype, f"O ramp {ramp}", scale=2.0, oracle=oo)
+        for name, x, r, orc in (("dQ", dq, dq_r, odq), ("dK", dk, dk_r, odk), ("dV", dv, dv_r, odv)):
             assert torch.isfinite(x).all()
-            U.assert_close(x.float().cpu().numpy(), r.cpu().numpy(), dtype, f"{name} ramp {ramp} causal {causal}", scale=4.0)
+            U.assert_close(x.float().cpu().numpy(), r.cpu().numpy(), dtype, f"{name} ramp {ramp} causal {causal}", scale=4.0, oracle=orc)
 
 
 def test_nonfinite_scores_propagate_like_fp32_math(gpu):
