@@ -32,7 +32,7 @@ LIB_NAME = "libflash_attn_gfx950.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 EXT_PATH = os.path.join(PKG, "_C.so")
 
-HIP_SOURCES = ["fa_fwd_pp.hip", "fa_bwd.hip", "fa_bwd_dkdv_pp.hip", "fa_capi.hip"]
+HIP_SOURCES = ["fa_fwd_pp.hip", "fa_bwd.hip", "fa_capi.hip"]
 EXTRA_FLAGS = {}      # per-file extra flags (none at present)
 HIP_HEADERS = ["fa_device.hpp", "fa_params.hpp", "fa_bwd_dkdv_common.hpp", os.path.join(INCLUDE, "flash_attn_gfx950.h")]
 # -amdgpu-mfma-vgpr-form: builtin MFMAs keep their result in VGPRs even in kernels that may use the

@@ -23,7 +23,6 @@
 //     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312); with caller-provided fp32 scratch the group is
 //     split over workgroups when the grid would otherwise be small or causally unbalanced;
 //   * operands that never change inside a kernel's loop live in registers (Q / dO fragments in dQ, K and part of V in dK/dV).
-#include <stdlib.h>
 #include <type_traits>
 #include "fa_bwd_dkdv_common.hpp"
 
@@ -107,15 +106,15 @@ template <typename T, int D, bool CAUSAL>
 #define FA_KV_VREG(D) ((D) == 128 ? 2 : 0)
 #endif
 #define FA_KV_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
-// dK/dV, D = 128: who issues the Q / dO tile DMA, and when.  Per-phase s_memtime stamps (tools/phase_timing_dkdv.py,
-// profiles/r3_dkdv_phase_timing.log) showed the two q-half groups badly out of balance: waves 0-3 (dispatched first = older = win every
-// arbitration) finish a tile ~1000 cycles before waves 4-7 and park at the barrier, while every wave pays 450-600 cycles at the top of
-// the iteration to issue its four 1-KiB DMA pieces with the matrix pipe idle.  1: waves 0-3 issue ALL pieces of tile t+2 at the END of
-// their tile t, in the time they would otherwise spend waiting; the rings are 3 deep for that (the third slot is the K tile's home,
-// free once K sits in registers).  0: every wave issues its share of tile t+1 at the top of iteration t (2-deep rings; D = 64).
-#ifndef FA_KV_TAIL_DMA
-#define FA_KV_TAIL_DMA(D) 0
-#endif
+// dK/dV: when the Q / dO tile DMA is issued.  Per-phase s_memtime stamps (tools/phase_timing_dkdv.py, profiles/r3_dkdv_phase_timing.log):
+// an LDS-DMA piece costs the issuing wave ~110 cycles, and with every wave issuing its pieces at the top of the iteration both waves
+// of a SIMD are in that phase together - the matrix pipe idles through it.  1: waves 4-7 issue theirs AFTER their S / dP MFMAs, while
+// waves 0-3 (which issue at the top) are still in that phase: -0..1 % at D = 128, -10 % at D = 64 causal (profiles/r3_dkdv_ab.log).
+// Measured and removed in round 3 (same log): waves 0-3 issuing ALL pieces at the end of their tile in the ~1000 cycles they wait
+// at the barrier (3-deep rings through the K tile's region: +-0 non-causal, +3..5 % causal), and a two-group ping-pong schedule of
+// the whole kernel (one phase apart, 3-deep rings, hand-pipelined phases: +3..39 % - a wave ALONE on the matrix pipe is latency-
+// bound on its LDS fragments, the lock-step pair hides each other's round trips, and 128 + 128 registers leave no room to
+// prefetch deeper; history: commit 9a378a6).
 #ifndef FA_KV_PF2
 #define FA_KV_PF2 3             // dV / dK phase: transposed fragments in flight
 #endif
@@ -401,10 +400,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     constexpr int TILEB = kKvBlockM * ROWB;                 // one Q (or dO) tile
     constexpr int STATB = 2 * kKvBlockM * 4;                // lse2 + dsum of one tile
     constexpr int OFF_V = KVB, OFF_Q = 2 * KVB, OFF_DO = 2 * KVB + 2 * TILEB, OFF_STAT = 2 * KVB + 4 * TILEB;
-    constexpr bool kTail = FA_KV_TAIL_DMA(D);
-    constexpr int RING = kTail ? 3 : 2;
-    static_assert(!kTail || 2 * TILEB <= KVB, "the third ring slots live in the K tile's region");
-    __shared__ __attribute__((aligned(16))) char smem_raw[OFF_STAT + RING * STATB];   // the only LDS object
+    __shared__ __attribute__((aligned(16))) char smem_raw[OFF_STAT + 2 * STATB];   // the only LDS object
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
     FA_LDS char* ktile = smem;
     FA_LDS char* vtile = smem + OFF_V;
@@ -465,17 +461,12 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
         return (uint32_t)row * rowb + lds_tile_logical_slot<D>(row, phys) * 16;
     };
     const uint32_t lds0 = lds_addr(smem);
-    // kTail: wave w < 4 moves pieces w, w + 4, w + 8, w + 12 of BOTH tensors; pieces 4 apart are 16 rows apart and share their swizzle,
-    // so one per-lane offset per tensor is enough and the rest goes into the instruction's scalar offset
     uint32_t q_src[PPW_Q], do_src[PPW_Q];                  // per-lane source offsets of this wave's Q/dO pieces
 #pragma unroll
     for (int i = 0; i < PPW_Q; ++i) {
-        q_src[i] = piece_src(kTail ? (wave & 3) : wave * PPW_Q + i, q_rowb);
-        do_src[i] = piece_src(kTail ? (wave & 3) : wave * PPW_Q + i, do_rowb);
+        q_src[i] = piece_src(wave * PPW_Q + i, q_rowb);
+        do_src[i] = piece_src(wave * PPW_Q + i, do_rowb);
     }
-    // ring slot -> LDS offset of the Q / dO tile (kTail: slot 2 = the K tile's region)
-    auto q_slot = [&](int s_) { return kTail && s_ == 2 ? 0 : OFF_Q + s_ * TILEB; };
-    auto do_slot = [&](int s_) { return kTail && s_ == 2 ? TILEB : OFF_DO + s_ * TILEB; };
 
     // rows read as MFMA operands with 8 contiguous d per lane (row reads): row l31 (+32*block), slot 2*ks+hi
     uint32_t row_rd[KS];
@@ -523,22 +514,12 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     // Q/dO tile at the cursor -> ring slot buf by LDS-DMA issued from inline asm: nothing returns to a VGPR, hipcc has no reason to wait.
     auto issue_tile = [&](int buf) {
         const uint32_t m0 = (uint32_t)pf_m0();
-        if constexpr (kTail) {                              // (waves 0-3 only: the caller checks)
-            constexpr int NP = kKvBlockM * SLOTS / 64 / 4;  // pieces per wave and tensor (4 at D = 128)
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int piece = wave + 4 * i;
-                dma16_to_lds_hidden_soff(q_srd, q_src[0], (m0 + 16u * i) * q_rowb, lds0 + q_slot(buf) + piece * 1024);
-                dma16_to_lds_hidden_soff(do_srd, do_src[0], (m0 + 16u * i) * do_rowb, lds0 + do_slot(buf) + piece * 1024);
-            }
-        } else {
 #pragma unroll
             for (int i = 0; i < PPW_Q; ++i) {
                 const int piece = wave * PPW_Q + i;
                 dma16_to_lds_hidden(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
                 dma16_to_lds_hidden(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
             }
-        }
     };
     // Statistics of the tile at the cursor: loaded when the tile's DMA is issued, transformed (-LSE*log2e, -D) and written to the stats
     // slot at the END of the same iteration, in front of the vmcnt(0) that is there anyway.  The consumers then need no per-element
@@ -565,7 +546,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     }
     if (n_iters > 0) {
         set_head(pf_head);
-        if (!kTail || qh == 0) issue_tile(0);
+        issue_tile(0);
         if (wave < 2) store_stat(load_stat(true), 0);
         pf_advance();
     }
@@ -582,39 +563,22 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
     for (int ks = 0; ks < VREG; ++ks) vreg[ks] = lds_read16(vtile, row_rd[ks] + kb * 32 * ROWB);
 
-    float st_tail = 0.f;                                    // kTail: statistics of the tile in flight (waves 0 / 1)
-    if constexpr (kTail) {
-        // K is in registers everywhere before anything lands in its region: the reads have returned (the empty asm pins them), then a barrier
-#pragma unroll
-        for (int ks = 0; ks < KREG; ++ks) asm volatile("" : "+v"(kreg[ks < KREG ? ks : 0]));
-        __syncthreads();
-        const bool more = n_iters > 1;                      // tile 1 -> slot 1, awaited at the end of iteration 0
-        if (qh == 0 && more) issue_tile(1);
-        st_tail = load_stat(more);
-        if (more) pf_advance();
-    }
 #ifdef FA_KV_TIMING
     uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef FA_ABL_KV_PP     // timing-only ablation (WRONG results: the 2-deep ring is not safe under the offset): q-half groups half an iteration apart
-    if (qh == 1) __syncthreads();
-#endif
-    int cur_tile = 0, ring_slot = 0;                        // tile-in-head index / ring slot (kTail) of the tile being computed
+    int cur_tile = 0;                                       // tile-in-head index of the tile being computed
     for (int it = 0; it < n_iters; ++it) {
         const int m0 = (qt_begin + cur_tile) * kKvBlockM;
         if (++cur_tile == tiles_per_head) cur_tile = 0;
-        const int buf = kTail ? ring_slot : (it & 1);
-        FA_LDS char* qbuf = smem + q_slot(buf);
-        FA_LDS char* dobuf = smem + do_slot(buf);
+        const int buf = it & 1;
+        FA_LDS char* qbuf = smem + OFF_Q + buf * TILEB;
+        FA_LDS char* dobuf = smem + OFF_DO + buf * TILEB;
         FA_LDS char* sbuf = stat + buf * STATB;
         const bool more = (it + 1 < n_iters);
         FA_KV_STAMP(5);                                     // (loop edge + barrier exit)
-        float st_next = 0.f;
-        if constexpr (!kTail) {
-            if (more && (!FA_KV_STAGGER_DMA || qh == 0)) issue_tile(buf ^ 1);      // ring slot buf^1 was last read in iteration it-1
-            st_next = load_stat(more);
-            if (!FA_KV_STAGGER_DMA && more) pf_advance();
-        }
+        if (more && (!FA_KV_STAGGER_DMA || qh == 0)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1
+        const float st_next = load_stat(more);
+        if (!FA_KV_STAGGER_DMA && more) pf_advance();
         FA_KV_STAMP(0);                                     // DMA issue
 
         // wave-level causal skip: all 32 rows of this wave's half are above the diagonal for all its 32 keys
@@ -656,13 +620,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 dpacc = LP<T>::mfma(da, vf, dpacc);                 // dP = dO V^T
             }
             FA_KV_STAMP(1);                                 // S / dP MFMAs
-            if constexpr (!kTail && FA_KV_STAGGER_DMA) {    // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
+            if constexpr (FA_KV_STAGGER_DMA) {    // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
                 if (more && qh == 1) issue_tile(buf ^ 1);
                 if (more) pf_advance();
             }
-#ifdef FA_ABL_KV_PP
-            __syncthreads();
-#endif
             f32x16 pacc;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -709,26 +670,11 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
             }
         }
         FA_KV_STAMP(3);                                     // dV / dK MFMAs
-        if constexpr (kTail) {
-            // tile it+1 (requested one iteration ago) has landed and its statistics are in st_tail; then waves 0-3 request tile it+2
-            // into the slot of tile it-1 - every wave left that tile behind at the previous barrier - and go to the barrier
-            const int slot1 = ring_slot == 2 ? 0 : ring_slot + 1, slot2 = ring_slot == 0 ? 2 : ring_slot - 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FA_KV_STAMP(4);
-            if (more && wave < 2) store_stat(st_tail, slot1);
-            asm volatile("" :: "v"(st_tail));
-            const bool more2 = it + 2 < n_iters;
-            if (qh == 0 && more2) issue_tile(slot2);
-            st_tail = load_stat(more2);
-            if (more2) pf_advance();
-            ring_slot = slot1;
-        } else {
             if (more && wave < 2) store_stat(st_next, buf ^ 1);
             asm volatile("" :: "v"(st_next));               // consumed on every path: hipcc never has to guard the register at the loop top
             // (timing-only ablations, profiles/r2_bwd_dkdv_lds_ab.log: without this wait -0.2 %, without wait AND barrier -5..-6 %)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
             FA_KV_STAMP(4);                                 // vmcnt wait
-        }
         __syncthreads();
     }
 #ifdef FA_KV_TIMING
@@ -739,9 +685,6 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     }
 #endif
 
-#ifdef FA_ABL_KV_PP
-    if (qh == 0) __syncthreads();
-#endif
     // ---- epilogue (fa_bwd_dkdv_common.hpp): the loop's last barrier has passed, K/V tiles, rings and stats are dead, LDS is scratch ----
     dkdv_epilogue<T, D, OFF_STAT>(p, smem, dkacc, dvacc, batch, head_k, split, k_row0, n0, keys_here, dk_base, dv_base);
 }
@@ -797,26 +740,13 @@ static hipError_t launch_dq_t(const BwdKernelParams& kp, hipStream_t s) {
     else hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, false>), dim3(grid), dim3(kDqThreads), 0, s, kp);
     return hipGetLastError();
 }
-// FA_DKDV_LOCKSTEP=1 in the environment (read once): D = 128 keeps the lock-step kernel - the in-process A/B switch of tools/ab_env.py
-static bool dkdv_lockstep_forced() {
-#ifdef FA_DKDV_FORCE_LOCKSTEP          // tools/build_variant.py: the A/B arm that keeps the lock-step kernel at D = 128
-    return true;
-#endif
-    static const bool v = [] { const char* e = getenv("FA_DKDV_LOCKSTEP"); return e != nullptr && e[0] == '1'; }();
-    return v;
-}
 template <typename T, int D>
 static hipError_t launch_dkdv_t(const BwdKernelParams& kp, hipStream_t s) {
     const uint32_t grid = (kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h_k : kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k) * (uint32_t)kp.n_split;
     if (grid == 0) return hipSuccess;
-    hipError_t e;
-    if (D == 128 && !dkdv_lockstep_forced()) {
-        e = launch_dkdv_pp(kp, std::is_same<T, _Float16>::value ? 0 : 1, grid, s);
-    } else {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-        else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-        e = hipGetLastError();
-    }
+    if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+    else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess || kp.n_split == 1) return e;
     const int64_t items = kp.ws_rows * kp.h_k * (D / 8);
     hipLaunchKernelGGL((fa_bwd_sum_splits_kernel<T, D>), dim3((uint32_t)((items + kSumThreads - 1) / kSumThreads)), dim3(kSumThreads), 0, s, kp);

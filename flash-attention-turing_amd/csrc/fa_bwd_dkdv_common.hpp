@@ -1,5 +1,6 @@
-// fa_bwd_dkdv_common.hpp — what the two dK/dV kernels share (fa_bwd.hip: the lock-step kernel, still used at D = 64;
-// fa_bwd_dkdv_pp.hip: the two-group ping-pong kernel for D = 128): the workgroup shape and the epilogue.
+// fa_bwd_dkdv_common.hpp — workgroup shape and epilogue of the dK/dV kernel (fa_bwd.hip), kept apart from the tile loop so that
+// alternative schedules of that loop can share them (round 3 measured a two-group ping-pong schedule against the lock-step one:
+// profiles/r3_dkdv_ab.log).
 #pragma once
 #include "fa_device.hpp"
 #include "fa_params.hpp"
@@ -106,8 +107,5 @@ FA_DEV void dkdv_epilogue(const BwdKernelParams& p, FA_LDS char* smem, f32x16 (&
     reduce_to_workspace(dkacc, 0);
     reduce_to_workspace(dvacc, 1);
 }
-
-// the D = 128 ping-pong kernel (fa_bwd_dkdv_pp.hip)
-hipError_t launch_dkdv_pp(const BwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t s);
 
 }  // namespace fa

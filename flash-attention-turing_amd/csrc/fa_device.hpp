@@ -181,20 +181,6 @@ FA_DEV void dma16_to_lds_hidden(const srd_t& srd, uint32_t voffset, uint32_t lds
     }
 }
 
-// Same, with a wave-uniform byte offset in the instruction's SGPR operand: one per-lane offset register serves every piece of a tile
-// whose source rows are a fixed distance apart (pieces p and p + 4 of a D = 128 tile are 16 rows apart and share their swizzle).
-template <bool SAVE_M0 = true>
-FA_DEV void dma16_to_lds_hidden_soff(const srd_t& srd, uint32_t voffset, uint32_t soffset, uint32_t lds_byte_addr) {
-    if constexpr (SAVE_M0) {
-        uint32_t keep;
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soffset)) : "memory");
-    } else {
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "v"(voffset), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soffset)) : "memory");
-    }
-}
-
 FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }
 FA_DEV void lds_write16(FA_LDS char* base, uint32_t off, u32x4 v) { *(FA_LDS u32x4*)(base + off) = v; }
 FA_DEV void lds_write8(FA_LDS char* base, uint32_t off, u32x2 v) { *(FA_LDS u32x2*)(base + off) = v; }
