@@ -93,6 +93,9 @@ template <typename T, int D, bool CAUSAL>
 // 0.80-0.90x time, dQ alone 0.90-0.98x, both 0.78-0.83x on every D = 64 shape (8k / 2k / 512, causal or not, GQA); D = 128
 // unchanged (its registers and LDS allow one workgroup per CU only).
 #define FA_DQ_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+#ifndef FA_DQ_STAGGER_DMA
+#define FA_DQ_STAGGER_DMA 1
+#endif
 #ifndef FA_DQ_NO_UNROLL
 #define FA_DQ_NO_UNROLL 0
 #endif
@@ -269,8 +272,11 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
         FA_LDS char* kbuf = smem + BUF * TILEB;
         FA_LDS char* vbuf = smem + 2 * TILEB + BUF * TILEB;
         __syncthreads();      // tile t is in LDS (every wave waited for its pieces); the other buffer is free again
-        if (t + 1 < n_tiles) dma_tiles(t + 1, BUF ^ 1);
+        // An LDS-DMA piece costs the issuing wave ~110 cycles (profiles/r3_dkdv_phase_timing.log): with FA_DQ_STAGGER_DMA waves 4-7 issue
+        // theirs after the first 32-key half below, while waves 0-3 (which issue here) are in their MFMAs, instead of all eight at once
         const bool wave_active = !CAUSAL || (n0 <= wave_q_hi + delta);
+        const bool dma_late = FA_DQ_STAGGER_DMA && wave >= 4 && wave_active;       // (a wave that skips this tile issues at once)
+        if (t + 1 < n_tiles && !dma_late) dma_tiles(t + 1, BUF ^ 1);
         if (wave_active) {
             // Masking is 2 VALU per score element (compare with an immediate + select), not 4: the key index of
             // element (bi, r) is n0 + 32*bi + (r&3) + 8*(r>>2) + 4*hi, so everything lane- or tile-dependent
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
                         sacc[r] = pv * (dpacc[r] - dsum);
                     }
                 }
+                if (bi == 0 && dma_late && t + 1 < n_tiles) dma_tiles(t + 1, BUF ^ 1);
                 // dQ^T (D x 32 queries) += K^T (D x 32 keys) * dS^T (32 keys x 32 queries)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {

@@ -37,7 +37,6 @@ namespace fa {
 
 constexpr int kFwdThreads = 512;
 constexpr int kFwdBlockM = 256;
-constexpr int kFwdBlockN = 64;
 
 constexpr float kPpDeferLog2 = 6.0f;
 
@@ -45,7 +44,15 @@ constexpr float kPpDeferLog2 = 6.0f;
 // instance fitted 128 registers anyway; the causal one took 140 and silently ran one workgroup per CU.  Forcing 128 costs no
 // spill and no extra instruction in any loop; interleaved A/B, causal forward (profiles/r1_fwd_d64_occupancy_ab.log):
 // 0.90-0.93x time at 8k, 0.96x at 16k, 0.75x at 2k, 0.71x at 512; non-causal and D = 128 unchanged; outputs bit-identical.
-#define FA_PP_MIN_WAVES(D) ((D) == 64 ? 4 : 2)
+#define FA_PP_MIN_WAVES(D, BN) ((D) == 64 && (BN) == 64 ? 4 : 2)
+// Keys per tile.  D = 128: 64.  D = 64: 128 since round 3 - the same 16 KiB tiles, 32 MFMAs per matrix phase and one workgroup per CU
+// as the D = 128 kernel (the reference picks a wider tile for d = 64 too, flash_fwd_launch_template.h:102-111).  With 64-key tiles a
+// D = 64 matrix phase is only 16 MFMAs (512 cycles), and the per-tile costs that do not shrink with D - two barriers, two DMA pieces
+// at ~110 cycles each per wave, the phase hand-over - weigh twice as much; FA_FWD_D64_BN=64 keeps the round-2 shape (two workgroups
+// per CU on 128 registers) for A/B (profiles/r3_fwd_d64_tile_ab.log).
+#ifndef FA_FWD_D64_BN
+#define FA_FWD_D64_BN 128
+#endif
 // Matrix phase = NPV P*V steps, then NQK QK^T steps.  P*V step j -> (output block db = j % DB, key sub-tile ts = j / DB): consecutive
 // MFMAs go to different accumulators (per accumulator the ts order, hence the result, is unchanged; 0.3-0.5 % over db-major at D = 128;
 // alternating P*V and QK^T steps measured the same, profiles/r2_fwd_step_order_ab.log).
@@ -54,7 +61,7 @@ constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PV_DB(j) ((j) % DB)
 #define FA_PV_TS(j) ((j) / DB)
 #ifndef FA_PP_OPTIMISTIC
-#define FA_PP_OPTIMISTIC(D, CAUSAL) ((D) == 128 || !(CAUSAL))      // D = 64 causal: the extra path does not fit its 128 registers
+#define FA_PP_OPTIMISTIC(D, CAUSAL, BN) ((D) == 128 || (BN) == 128 || !(CAUSAL))      // D = 64 causal with 64-key tiles: the extra path does not fit its 128 registers
 #endif
 
 // One workgroup = one 256-row query tile of one (batch, head).  Two multi-item variants were built and measured in round 2 and are
@@ -65,9 +72,10 @@ constexpr float kPpDeferLog2 = 6.0f;
 // were SLOWER: hipcc gives the tile loop a worse register allocation once it sits inside an item loop (persistent: kernel arguments
 // of the next head stay live across it, loop descriptors get spilled, LDS reads serialise: 1.27-1.7x; pairs: 256 VGPRs + 30
 // spilled, 1.02-1.05x at 4k-16k, 1.26x at causal 1k, and half the grid at 512).  profiles/r2_fwd_pair_mode_ab.log.
-template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_kernel(const FwdKernelParams p) {
+template <typename T, int D, bool CAUSAL, int BN>
+__global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp_kernel(const FwdKernelParams p) {
     constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, SLOTS = D / 8;
+    constexpr int kFwdBlockN = BN, NB = BN / 32, NTS = BN / 16;      // keys per tile; 32-key score blocks / 16-key P fragments per tile
     constexpr int TILEB = kFwdBlockN * ROWB;
     constexpr int RING = 3;
     constexpr int RINGB = 2 * RING * TILEB, STAGEB = kFwdBlockM * ROWB;     // D = 128: 96 KiB + 64 KiB = all 160 KiB of the CU
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // the DPW 1-KiB pieces [w*DPW, (w+1)*DPW) of every K / V tile and the XOR swizzle is applied to the per-lane SOURCE offset.
     // Every LDS-DMA of this kernel is issued from inline asm (fa_device.hpp:dma16_to_lds_hidden): hipcc never sees one, so it never
     // parks a vmcnt(0) in front of an LDS read; completion is the explicit vmcnt(0) that ends every softmax phase.
-    constexpr int DPW = SLOTS / 8;            // DMA instructions per wave per tile (2 for d=128, 1 for d=64)
+    constexpr int DPW = BN * SLOTS / 512;     // DMA instructions (1 KiB pieces) per wave per tile: 2 (1 for D = 64 with 64-key tiles)
     uint32_t dma_goff_k[DPW], dma_goff_v[DPW];
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     __syncthreads();
     if (group == 1) __syncthreads();          // group B runs one phase behind group A, for the whole life of the workgroup
 
-    f32x16 sacc[2];
-    u32x4 pf[4];
+    f32x16 sacc[NB];
+    u32x4 pf[NTS];
     int wave_q_lo = m0 + wave * 32, wave_q_hi = wave_q_lo + 31;
 
     // ---- phase bodies ---------------------------------------------------------------------------
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int ts = 0; ts < 4; ++ts) {
+            for (int ts = 0; ts < NTS; ++ts) {
                 const u32x2 a0 = lds_read_tr8(vbuf, v_rd[0][db] + ts * 16 * ROWB);
                 const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
                 const u32x4 vf = {a0.x, a0.y, a1.x, a1.y};
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     auto qk_step = [&]() __attribute__((always_inline)) {                            // S(u)^T = K(u) Q^T
         FA_LDS char* kbuf = kring + ring_u * TILEB;
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi) {
+        for (int bi = 0; bi < NB; ++bi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
 #pragma unroll
@@ -232,8 +240,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
     // phase starts on an MFMA instead of on an LDS round trip.  Measured with per-phase s_memtime stamps (tools/phase_timing.py,
     // profiles/r2_fwd_phase_timing.log): the period of the ping-pong is the SUM of the two groups' matrix phases (the softmax
     // phases hide behind them), and a matrix phase took 1270 cycles for 1024 cycles of MFMA issue.
-    constexpr bool kOptimistic = FA_PP_OPTIMISTIC(D, CAUSAL);
-    constexpr int NPV = 4 * DB, NQK = 2 * KS, NST = NPV + NQK, PF = (D == 64) ? 2 : 4;      // fragments in flight (3 / 6 / 8 measured within 0.5 % of 4); D = 64 has 128 VGPRs only
+    constexpr bool kOptimistic = FA_PP_OPTIMISTIC(D, CAUSAL, BN);
+    constexpr int NPV = NTS * DB, NQK = NB * KS, NST = NPV + NQK, PF = (D == 64 && BN == 64) ? 2 : 4;      // fragments in flight (3 / 6 / 8 measured within 0.5 % of 4); D = 64 with 64-key tiles has 128 VGPRs only
     auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
         if (FA_STEP_IS_PV(j)) {
             const int pj = FA_STEP_IDX(j), db = FA_PV_DB(pj), ts = FA_PV_TS(pj);
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             const u32x2 a1 = lds_read_tr8(vbuf, v_rd[1][db] + ts * 16 * ROWB);
             return u32x4{a0.x, a0.y, a1.x, a1.y};
         }
-        const int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
+        const int i = FA_STEP_IDX(j), ks = i / NB, bi = i % NB;
         return lds_read16(kring + slot_k * TILEB, k_rd[ks] + bi * 32 * ROWB);
     };
     // read bases with the ring origin folded in and hidden from the compiler: with compile-time ring slots every fragment read is
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             const u32x2 a1 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_abs[1][db], slot_v * TILEB + ts * 16 * ROWB);
             return u32x4{a0.x, a0.y, a1.x, a1.y};
         }
-        const int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
+        const int i = FA_STEP_IDX(j), ks = i / NB, bi = i % NB;
         return lds_read16((const FA_LDS char*)(uintptr_t)k_abs[ks], slot_k * TILEB + bi * 32 * ROWB);
     };
     u32x4 pre[PF];
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                 constexpr int pj = FA_STEP_IDX(j);
                 oacc[FA_PV_DB(pj)] = LP<T>::mfma(fr[j], pf[FA_PV_TS(pj)], oacc[FA_PV_DB(pj)]);
             } else {
-                constexpr int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
+                constexpr int i = FA_STEP_IDX(j), ks = i / NB, bi = i % NB;
                 if constexpr (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             if (need_mask) {
                 const int lim = CAUSAL ? min(sk - 1, m0 + q_row + delta) : sk - 1;
 #pragma unroll
-                for (int bi = 0; bi < 2; ++bi)
+                for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = n0 + 32 * bi + c_row(r, hi);
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             const float mc0 = m_run * c;
             float ps = 0.f;
 #pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
+            for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const float p0 = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc0)), p1 = fast_exp2(__builtin_fmaf(sacc[bi][r + 1], c, -mc0));
@@ -339,9 +347,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         }
         float mx = sacc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+        for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[bi][r]);
         mx = max_both_halves(mx);
         float psum = 0.f;
         {
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
             // instructions -- measured 5 % SLOWER next to the partner wave's MFMAs)
             const float mc = m_run * c;
 #pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
+            for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float pv = fast_exp2(__builtin_fmaf(sacc[bi][r], c, -mc));
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                 }
         }
 #pragma unroll
-        for (int ts = 0; ts < 4; ++ts) pf[ts] = pack_c_half<T>(sacc[ts >> 1], ts & 1);
+        for (int ts = 0; ts < NTS; ++ts) pf[ts] = pack_c_half<T>(sacc[ts >> 1], ts & 1);
         l_run += psum;
     };
     auto advance_ring = [&]() __attribute__((always_inline)) {
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
                         constexpr int pj = FA_STEP_IDX(j);
                         oacc[FA_PV_DB(pj)] = LP<T>::mfma(fr[j], pf[FA_PV_TS(pj)], oacc[FA_PV_DB(pj)]);
                     } else {
-                        constexpr int i = FA_STEP_IDX(j), ks = i / 2, bi = i % 2;
+                        constexpr int i = FA_STEP_IDX(j), ks = i / NB, bi = i % NB;
                         if constexpr (ks == 0) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) sacc[bi][r] = 0.f;
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
         using i1 = std::integral_constant<int, 1>;
         using i2 = std::integral_constant<int, 2>;
         u = 1;
-        if constexpr (D == 128) {                 // (D = 64 runs two workgroups per CU on 128 registers: no room for the extra bases)
+        if constexpr (D == 128 || BN == 128) {    // (D = 64 with 64-key tiles runs two workgroups per CU on 128 registers: no room for the extra bases)
             for (; u + 3 <= n_main; u += 3) {
                 step_c(u, i0{}, i1{}, i2{});
                 step_c(u + 1, i1{}, i2{}, i0{});
@@ -497,8 +505,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D)) void fa_fwd_pp_ker
 template <typename T, int D>
 static hipError_t launch_pp_t(const FwdKernelParams& kp, uint32_t grid, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
-    if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
-    else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    constexpr int BN = D == 64 ? FA_FWD_D64_BN : 64;
+    if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, BN>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, BN>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
     return hipGetLastError();
 }
 
