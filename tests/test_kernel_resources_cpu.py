@@ -69,8 +69,8 @@ def test_d64_kernels_fit_two_workgroups_per_cu(kernels):
             assert info["occupancy"] >= 4, (f, name, info["occupancy"], info["vgprs"], info["agprs"])
             assert 2 * info["lds_bytes"] <= 160 * 1024, (f, name, info["lds_bytes"])
     assert seen == 8, seen
-    fwd64 = [n for (f, n) in kernels if "fa_fwd_pp_kernel" in n and "Li64E" in n]
-    assert len(fwd64) == 4 and all("Li128EEE" in n for n in fwd64), fwd64       # <T, 64, CAUSAL, BN = 128>
+    fwd64 = [n for (f, n) in kernels if "fa_fwd_pp_kernel" in n and "Li64ELb" in n]                  # <T, D = 64, CAUSAL, BN>
+    assert len(fwd64) == 4 and all(n.count("Li128E") == 1 for n in fwd64), fwd64                    # BN = 128
 
 
 def test_forward_kernels_touch_m0_only_in_their_own_lds_dma_statements(kernels):
