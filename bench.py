@@ -328,6 +328,16 @@ class PowerSampler:
         return out
 
 
+def build_commit():
+    """git commit the tree was built from (tools/gpu.sh leaves it next to the package: .git does not travel to the GPU box); None when
+    the file is absent (the library's source digest is the authoritative tie between kernels and profiles)"""
+    try:
+        with open(os.path.join(ROOT, "flash-attention-turing_amd", "BUILD_COMMIT")) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
 def library_source_digest(capi):
     """`src=<12 hex>` of fa_build_info(): sha256 over kernel sources + headers + flags, stamped in by build.py"""
     import re
@@ -643,6 +653,19 @@ def main():
         for v_ in gq.values():
             v_["vs_mha"] = v_["bwd_ms"] / gq["h32_hk32"]["bwd_ms"]
         extra["gqa_bwd_b4_s8192_d128_bf16_causal"] = gq
+        # head_dim 64, the reference's other instantiation (flash_*_hdim64_*): b4 s8192 h32 fp16, forward and backward
+        d64 = {}
+        for cz in (False, True):
+            et = make_inputs(torch, device, 4, 8192, 32, 32, 64, "fp16", 4321, True)
+            f = lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], cz)
+            g = lambda: capi.mha_bwd(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"], et["dv"], et["dsum"], cz)
+            f(); g(); sync()
+            fms, bms = event_time_ms(torch, f, 5, reps=5), event_time_ms(torch, g, 3, reps=5)
+            ff = fwd_flops(4, 8192, 8192, 32, 64, cz)
+            d64["causal" if cz else "noncausal"] = {"fwd_ms": fms, "fwd_tflops": ff / fms / 1e9, "bwd_ms": bms, "bwd_tflops": 2.5 * ff / bms / 1e9}
+            del et
+            torch.cuda.empty_cache()
+        extra["d64_b4_s8192_h32_fp16"] = d64
         # seqlen sweep of the reference's published chart (README.md:7-16): b4 h32 d128
         for cz in (False, True):
             sweep = {}
@@ -689,7 +712,7 @@ def main():
                        "global_batch": b * dist.world, "seq_len": s, "parallelism": f"batch-sharded x{dist.world}, no collective",
                        "flops_def": "4*b*h*sq*sk*d (x0.5 causal) [SURVEY.md 8d]"},
             "frac_of_fp16_mfma_peak": value / (PEAK_DENSE_FP16_TFLOPS * dist.world),
-            "comm_backend": comm_backend, "library": capi.lib().fa_build_info().decode(),
+            "comm_backend": comm_backend, "library": capi.lib().fa_build_info().decode(), "git_commit": build_commit(),
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
             "device": {"name": prop.name or getattr(prop, "gcnArchName", ""), "arch": getattr(prop, "gcnArchName", ""), "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,
                        "peak_used_tflops": PEAK_DENSE_FP16_TFLOPS},
