@@ -239,6 +239,18 @@ def test_flash_attn_func_autograd_and_strided_views(gpu):
     U.assert_close(q.grad.float().cpu().numpy(), dq_r.cpu().numpy(), "fp16", "dQ")
     U.assert_close(k.grad.float().cpu().numpy(), dk_r.cpu().numpy(), "fp16", "dK")
     U.assert_close(v.grad.float().cpu().numpy(), dv_r.cpu().numpy(), "fp16", "dV")
+    # a strided (head-sliced) dout reaches the kernels as it is: no hidden .contiguous() copy, bit-identical gradients
+    dbig = torch.zeros(2, 200, 8, 128, device=gpu, dtype=torch.float16)
+    dbig[:, :, 2:6] = do
+    dview = dbig[:, :, 2:6]
+    assert not dview.is_contiguous()
+    g_dense = (q.grad.clone(), k.grad.clone(), v.grad.clone())
+    q.grad = k.grad = v.grad = None
+    copies = F._C.densify_copies()
+    F.flash_attn_func(q, k, v, causal=True).backward(dview)
+    assert F._C.densify_copies() == copies, "strided dout must not be densified"
+    for a_, b_ in zip(g_dense, (q.grad, k.grad, v.grad)):
+        assert torch.equal(a_, b_)
     # legacy README signature
     out2 = F.flash_attn_func(q, k, v, 2, 200, 4, 128)
     assert out2.shape == q.shape
