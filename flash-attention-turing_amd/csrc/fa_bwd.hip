@@ -119,8 +119,8 @@ template <typename T, int D, bool CAUSAL>
 // bound on its LDS fragments, the lock-step pair hides each other's round trips, and 128 + 128 registers leave no room to
 // prefetch deeper; history: commit 9a378a6).
 #ifndef FA_KV_PF2
-#define FA_KV_PF2 3             // dV / dK phase: transposed fragments in flight
-#endif
+#define FA_KV_PF2(D) ((D) == 64 ? 2 : 3)      // dV / dK phase: transposed fragments in flight (D = 64: 3 costs 2 spill ops per tile in its 64 + 64
+#endif                                        // registers; 4 at D = 128 measured +-1 %, profiles/r3_dkdv_ab.log)
 #ifndef FA_KV_STAGGER_DMA
 #define FA_KV_STAGGER_DMA 1
 #endif
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
                 dsfr[half] = pack_c_half<T>(sacc, half);            // dS rounded (:1360)
             }
             FA_KV_STAMP(2);                                 // exp / mask / dS / pack
-            constexpr int NST = 4 * DB, PF = FA_KV_PF2;                  // step j = (half, db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
+            constexpr int NST = 4 * DB, PF = FA_KV_PF2(D);                  // step j = (half, db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
             auto rd_frag = [&](int j) {
                 const int half = j / (2 * DB), db = (j >> 1) % DB, ts = 2 * qh + half;
                 FA_LDS char* src = (j & 1) ? qbuf : dobuf;
