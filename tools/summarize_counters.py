@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reduce the CSVs of tools/pmc_round.sh: per case and kernel, mean counter value per launch (summed over counter instances, first
+"""Reduce the shader-counter CSVs of tools/round_evidence.sh: per case and kernel, mean counter value per launch (summed over counter instances, first
 launch skipped), kernel time under the profiler, and a few derived figures: effective clock (GRBM_GUI_ACTIVE / 8 XCDs / time), MFMA
 pipe utilisation at that clock (SQ_VALU_MFMA_BUSY_CYCLES / 4 SIMDs per CU / 256 CUs / cycles), wave-cycle breakdown, LDS-array
 utilisation (SQ_LDS_IDX_ACTIVE / 256 CUs / cycles).  Usage: summarize_counters.py OUTDIR -> JSON on stdout"""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the CSVs of tools/profile_round.sh into per-kernel HBM traffic figures (bytes per launch):
+"""Turn the FETCH_SIZE / WRITE_SIZE CSVs of tools/round_evidence.sh into per-kernel HBM traffic figures (bytes per launch):
 FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1 KiB; per MI355X_MICROARCH.md (HBM / rocprofv3 section) FETCH_SIZE
 on gfx950 counts half the bytes of wide coalesced reads -> x2, WRITE_SIZE is used as is.  First launch of every kernel is skipped.
 Usage: summarize_pmc.py OUTDIR  -> JSON on stdout"""
