@@ -273,11 +273,20 @@ class PowerSampler:
 
         self.period, self.samples, self._stop, self._thr = period_s, [], threading.Event(), None
         self.power_path = self.sclk_path = self.cap_w = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        # (one GPU per box in this pool; with several, rank r reads the r-th card that exposes a power sensor)
-        cands = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
+        # the hwmon node of THIS device: /sys/class/drm/cardN/device is a link to its PCI function; match it against the bus id HIP reports
+        # (a container may show other GPUs' cards too, and reading a neighbour's sensors would be worse than reading none)
+        self.pci = self._pci_bus_id(device_index)
+        cands = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            try:
+                addr = os.path.basename(os.path.realpath(os.path.join(c, "device"))).lower()
+            except OSError:
+                continue
+            if self.pci and addr == self.pci:
+                cands = sorted(glob.glob(os.path.join(c, "device", "hwmon", "hwmon*")))
+                break
         if cands:
-            h = cands[min(device_index, len(cands) - 1)]
+            h = cands[0]
             for f in ("power1_average", "power1_input"):
                 if os.path.exists(os.path.join(h, f)):
                     self.power_path = os.path.join(h, f)
@@ -286,6 +295,20 @@ class PowerSampler:
                 self.sclk_path = os.path.join(h, "freq1_input")
             self.cap_w = (self._read(os.path.join(h, "power1_cap")) or 0.0) / 1e6 or None
         self._threading = threading
+
+    @staticmethod
+    def _pci_bus_id(device_index):
+        """'0000:bb:dd.f' of HIP device `device_index` (hipDeviceGetPCIBusId through ctypes), lower case; None if unavailable"""
+        import ctypes
+
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+                return None
+            return buf.value.decode().lower() or None
+        except OSError:
+            return None
 
     @staticmethod
     def _read(path):
@@ -314,11 +337,11 @@ class PowerSampler:
 
     def summary(self, t0, t1, what):
         if not (self.power_path or self.sclk_path):
-            return {"error": "no amdgpu hwmon power / sclk sensor visible under /sys/class/drm", "region": what}
+            return {"error": f"no amdgpu hwmon power / sclk sensor visible for this device (PCI {self.pci}) under /sys/class/drm", "region": what}
         inside = [x for x in self.samples if t0 <= x[0] <= t1]
         pw = [x[1] / 1e6 for x in inside if x[1] is not None]
         ck = [x[2] / 1e6 for x in inside if x[2] is not None]
-        out = {"region": what, "samples": len(inside), "sensor": self.power_path or self.sclk_path, "power_cap_w": self.cap_w,
+        out = {"region": what, "samples": len(inside), "sensor": self.power_path or self.sclk_path, "pci_bus_id": self.pci, "power_cap_w": self.cap_w,
                "note": "freq1_input is the clock the SMU reports (its target), not the delivered one: the effective clock under MFMA load "
                        "comes from GRBM_GUI_ACTIVE / time in profiles/*shader_pmc_summary.json"}
         if pw:

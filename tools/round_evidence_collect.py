@@ -34,6 +34,9 @@ def stats(directory):
     files = glob.glob(os.path.join(directory, "**", "*kernel_stats.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no kernel_stats.csv under {directory}")
+    if len(files) > 1:
+        raise SystemExit(f"{len(files)} kernel_stats.csv under {directory}: stale files of an earlier run were merged into it - `rm -rf` the evidence "
+                         "directory on the dev side before tools/round_evidence.sh (gpurun merges, it does not mirror)")
     out = {}
     with open(files[0]) as f:
         for row in csv.DictReader(f):
