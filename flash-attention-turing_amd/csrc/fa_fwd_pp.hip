@@ -45,14 +45,18 @@ constexpr float kPpDeferLog2 = 6.0f;
 // spill and no extra instruction in any loop; interleaved A/B, causal forward (profiles/r1_fwd_d64_occupancy_ab.log):
 // 0.90-0.93x time at 8k, 0.96x at 16k, 0.75x at 2k, 0.71x at 512; non-causal and D = 128 unchanged; outputs bit-identical.
 #define FA_PP_MIN_WAVES(D, BN) ((D) == 64 && (BN) == 64 ? 4 : 2)
-// Keys per tile.  D = 128: 64.  D = 64: 128 since round 3 - the same 16 KiB tiles, 32 MFMAs per matrix phase and one workgroup per CU
-// as the D = 128 kernel (the reference picks a wider tile for d = 64 too, flash_fwd_launch_template.h:102-111).  With 64-key tiles a
-// D = 64 matrix phase is only 16 MFMAs (512 cycles), and the per-tile costs that do not shrink with D - two barriers, two DMA pieces
-// at ~110 cycles each per wave, the phase hand-over - weigh twice as much; FA_FWD_D64_BN=64 keeps the round-2 shape (two workgroups
-// per CU on 128 registers) for A/B (profiles/r3_fwd_d64_tile_ab.log).
+// Keys per tile.  D = 128: 64.  D = 64: two shapes, picked by the launcher (the reference has a d = 64 tile of its own as well,
+// flash_fwd_launch_template.h:102-111):
+//   64 keys  - two workgroups per CU on 128 registers (round 2): one's prologue / epilogue hides behind the other's loop; better for
+//              every non-causal length (1-8 %) and for short causal ones;
+//   128 keys - the D = 128 structure (16 KiB tiles, 32 MFMAs per matrix phase, one workgroup per CU, x3-unrolled loop, optimistic
+//              softmax also under the mask): the per-tile costs that do not shrink with D (two barriers, DMA pieces at ~110 cycles
+//              each, the phase hand-over) weigh half as much; 5-9 % faster under a causal mask from 2k keys on.
+// Measured ladder 256 .. 16k, both shapes, causal or not: profiles/r3_fwd_d64_tile_ab.log.  -DFA_FWD_D64_BN=64 / 128 pins one shape (A/B).
 #ifndef FA_FWD_D64_BN
-#define FA_FWD_D64_BN 128
+#define FA_FWD_D64_BN 0
 #endif
+constexpr int kFwdD64WideMinKeys = 2048;
 // Matrix phase = NPV P*V steps, then NQK QK^T steps.  P*V step j -> (output block db = j % DB, key sub-tile ts = j / DB): consecutive
 // MFMAs go to different accumulators (per accumulator the ts order, hence the result, is unchanged; 0.3-0.5 % over db-major at D = 128;
 // alternating P*V and QK^T steps measured the same, profiles/r2_fwd_step_order_ab.log).
@@ -506,9 +510,16 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 template <typename T, int D>
 static hipError_t launch_pp_t(const FwdKernelParams& kp, uint32_t grid, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
-    constexpr int BN = D == 64 ? FA_FWD_D64_BN : 64;
-    if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, BN>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
-    else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, BN>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    if constexpr (D == 64) {
+        const bool wide = FA_FWD_D64_BN != 0 ? FA_FWD_D64_BN == 128 : (kp.is_causal && kp.seqlen_k >= kFwdD64WideMinKeys);
+        if (wide) {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, 64, true, 128>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+            else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, 64, false, 128>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+            return hipGetLastError();
+        }
+    }
+    if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    else hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
     return hipGetLastError();
 }
 

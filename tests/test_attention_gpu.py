@@ -201,6 +201,27 @@ def test_bf16_backward_medium(gpu):
         assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
 
 
+@pytest.mark.parametrize("sq,sk", [(2048, 2048), (2500, 2500), (1000, 3000), (2047, 2047), (300, 2048)])
+def test_d64_forward_tile_shapes(gpu, sq, sk):
+    """head_dim 64 dispatches between two forward tile shapes (fa_fwd_pp.hip: 128-key tiles under a causal mask from 2048 keys on,
+    64-key tiles otherwise): both sides of the switch, ragged tails and sq != sk, forward values and LSE against fp32 math, and the
+    backward fed by them."""
+    import flash_attn_turing as F
+
+    gen = torch.Generator(device="cpu").manual_seed(sq * 7 + sk)
+    q = torch.randn(2, sq, 4, 64, generator=gen).to(gpu, torch.float16)
+    k = torch.randn(2, sk, 2, 64, generator=gen).to(gpu, torch.float16)
+    v = torch.randn(2, sk, 2, 64, generator=gen).to(gpu, torch.float16)
+    do = torch.randn(2, sq, 4, 64, generator=gen).to(gpu, torch.float16)
+    for causal in (True, False):
+        o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, causal)
+        o, lse = F.fwd(q, k, v, causal)
+        dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
+        for got, ref, name in ((o, o_r, "O"), (dq, dq_r, "dQ"), (dk, dk_r, "dK"), (dv, dv_r, "dV")):
+            U.assert_close(got.float().cpu().numpy(), ref.cpu().numpy(), "fp16", f"{name} d64 sq={sq} sk={sk} causal={causal}", sk=sk)
+        assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
+
+
 def test_online_softmax_rescale_spike(gpu):
     """Force the running-max update late in the K loop (cdna guide rule 26): one key far
     larger than everything before it, at a chosen tile, for a subset of rows."""

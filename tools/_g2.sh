@@ -1,1 +1,2 @@
-python tools/ab_stage.py tools/abl/libfa_kv64pf3.so tools/abl/libfa_kv64pf2.so --stages dkdv --only "d64,c4 bf16" --rounds 7 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3b/ab_dkdv_d64_pf.log
+timeout 600 python -m pytest tests/test_attention_gpu.py -m gpu -q -x -k "d64_forward_tile or golden or oracle" 2>&1 | tail -3
+python tools/ab_fwd_seqs.py tools/abl/libfa_d64bn64.so tools/abl/libfa_d64bn128.so tools/abl/libfa_d64auto.so --d 64 --rounds 5 2>&1 | grep -v amdgpu.ids
