@@ -1,2 +1,4 @@
-timeout 600 python -m pytest tests/test_attention_gpu.py -m gpu -q -x -k "d64_forward_tile or golden or oracle" 2>&1 | tail -3
-python tools/ab_fwd_seqs.py tools/abl/libfa_d64bn64.so tools/abl/libfa_d64bn128.so tools/abl/libfa_d64auto.so --d 64 --rounds 5 2>&1 | grep -v amdgpu.ids
+mkdir -p gpurun_out/r3d gpurun_out/r3a
+timeout 1800 python -m pytest tests -m gpu -q -rf --tb=short > gpurun_out/r3a/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r3a/pytest.log
+python tools/sweep_efficiency.py > gpurun_out/r3d/sweep_efficiency.log 2>&1; echo "sweep rc=$?"
+bash tools/round_evidence.sh > gpurun_out/r3d/evidence_run.log 2>&1; tail -3 gpurun_out/r3d/evidence_run.log
