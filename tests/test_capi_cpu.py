@@ -161,3 +161,35 @@ def test_dkdv_workspace_rule_host_arithmetic():
     assert capi.lib().fa_bwd_dkdv(ctypes.byref(p), None) == capi.FA_ERR_BAD_SHAPE
     p.workspace_bytes = 64
     assert capi.lib().fa_bwd_dkdv(ctypes.byref(p), None) == capi.FA_ERR_BAD_STRIDE
+
+
+def test_header_is_valid_c_and_links_from_plain_c(tmp_path):
+    """include/flash_attn_gfx950.h is a C header: a C11 translation unit (gcc, no C++) includes it, fills the structs with FA_PARAMS_INIT,
+    links against the library and gets the host-side validation codes back - what a cgo / JNI / FFI binding of the reference would do."""
+    import os
+    import subprocess
+
+    src = tmp_path / "use_header.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "flash_attn_gfx950.h"
+int main(void) {
+    fa_fwd_params f; fa_bwd_params b;
+    FA_PARAMS_INIT(f); FA_PARAMS_INIT(b);
+    if (f.struct_size != sizeof(f) || b.magic != FA_PARAMS_MAGIC) return 10;
+    f.b = 1; f.seqlen_q = 8; f.seqlen_k = 8; f.h = 3; f.h_k = 2; f.d = 128; f.dtype = FA_FP16;
+    if (fa_run_mha_fwd(&f, NULL) != FA_ERR_BAD_GQA) return 11;
+    f.magic = 0;
+    if (fa_run_mha_fwd(&f, NULL) != FA_ERR_BAD_ABI) return 12;
+    if (fa_abi_version() != FA_ABI_VERSION) return 13;
+    printf("%s\n", fa_build_info());
+    return 0;
+}
+""")
+    exe = tmp_path / "use_header"
+    libdir = os.path.dirname(capi.LIBRARY_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.dirname(capi.HEADER_PATH), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:libflash_attn_gfx950.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert "abi=4" in out.stdout and "src=" in out.stdout
