@@ -1,4 +1,2 @@
-mkdir -p gpurun_out/r3d gpurun_out/r3a
-timeout 1800 python -m pytest tests -m gpu -q -rf --tb=short > gpurun_out/r3a/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r3a/pytest.log
-python tools/sweep_efficiency.py > gpurun_out/r3d/sweep_efficiency.log 2>&1; echo "sweep rc=$?"
-bash tools/round_evidence.sh > gpurun_out/r3d/evidence_run.log 2>&1; tail -3 gpurun_out/r3d/evidence_run.log
+python tools/ab_fwd_seqs.py tools/abl/libfa_fwd0.so tools/abl/libfa_fwdearly.so --d 128 --rounds 7 2>&1 | grep -v amdgpu.ids
+python tools/ab_stage.py tools/abl/libfa_fwd0.so tools/abl/libfa_fwdearly.so --stages fwd --only "c3 fp16,fp16 d128 1k,d128 512,d64 8k" --rounds 5 2>&1 | grep -v amdgpu.ids
