@@ -33,6 +33,24 @@ __global__ void k_tr(const int* lane_elem_off, unsigned short* out) {
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
 }
 
+// C = A(16x32) * B(32x16): assumed lane layout of v_mfma_f32_16x16x32_f16 (fa_fwd_pp16.hip):
+//   A: lane l holds row l & 15, k = 8 * (l >> 4) + j;  B: col l & 15, same k;  C: col l & 15, rows 4 * (l >> 4) + r, r = 0..3
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ void k_mfma16(const _Float16* A, const _Float16* B, float* C) {
+    int l = threadIdx.x, g = l >> 4, i = l & 15;
+    f16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = A[i * 32 + 8 * g + j]; b[j] = B[(8 * g + j) * 16 + i]; }
+    f32x4v c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) C[(4 * g + r) * 16 + i] = c[r];
+}
+__global__ void k_swap16(unsigned* out) {
+    unsigned a = 1000 + threadIdx.x, b = 2000 + threadIdx.x;
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    out[threadIdx.x * 2] = r[0];
+    out[threadIdx.x * 2 + 1] = r[1];
+}
+
 __global__ void k_swap(unsigned* out) {
     unsigned a = 1000 + threadIdx.x, b = 2000 + threadIdx.x;
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -97,6 +115,40 @@ int main() {
             if (out[2 * l] != e0 || out[2 * l + 1] != e1) { if (bad < 8) printf("   swap lane %d got (%u,%u) expect (%u,%u)\n", l, out[2*l], out[2*l+1], e0, e1); ++bad; }
         }
         printf("[probe] v_permlane32_swap semantics: %s\n", bad == 0 ? "PASS" : "FAIL");
+        fails += bad != 0;
+    }
+    {   // (4) MFMA 16x16x32 layout
+        std::vector<_Float16> A(16 * 32), B(32 * 16);
+        srand(5);
+        for (auto& x : A) x = (_Float16)((rand() % 17 - 8) / 4.0f);
+        for (auto& x : B) x = (_Float16)((rand() % 13 - 6) / 2.0f);
+        _Float16 *dA, *dB; float* dC;
+        CK(hipMalloc(&dA, A.size() * 2)); CK(hipMalloc(&dB, B.size() * 2)); CK(hipMalloc(&dC, 16 * 16 * 4));
+        CK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+        k_mfma16<<<1, 64>>>(dA, dB, dC);
+        std::vector<float> C(16 * 16);
+        CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+        double maxerr = 0;
+        for (int i = 0; i < 16; ++i) for (int n = 0; n < 16; ++n) {
+            double acc = 0; for (int k = 0; k < 32; ++k) acc += (double)A[i * 32 + k] * (double)B[k * 16 + n];
+            maxerr = fmax(maxerr, fabs(acc - C[i * 16 + n]));
+        }
+        printf("[probe] mfma_f32_16x16x32_f16 A/B/C layout: %s (max err %.3g)\n", maxerr < 1e-3 ? "PASS" : "FAIL", maxerr);
+        fails += !(maxerr < 1e-3);
+    }
+    {   // (5) permlane16_swap(a, b): expected r0 = {rows 0,2: own a; rows 1,3: b of lane-16}, r1 = {rows 0,2: a of lane+16; rows 1,3: own b}
+        unsigned* dOut; CK(hipMalloc(&dOut, 128 * 4));
+        k_swap16<<<1, 64>>>(dOut);
+        std::vector<unsigned> out(128);
+        CK(hipMemcpy(out.data(), dOut, 512, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int odd = (l >> 4) & 1;
+            unsigned e0 = !odd ? 1000 + l : 2000 + (l - 16);
+            unsigned e1 = !odd ? 1000 + (l + 16) : 2000 + l;
+            if (out[2 * l] != e0 || out[2 * l + 1] != e1) { if (bad < 8) printf("   swap16 lane %d got (%u,%u) expect (%u,%u)\n", l, out[2*l], out[2*l+1], e0, e1); ++bad; }
+        }
+        printf("[probe] v_permlane16_swap semantics: %s\n", bad == 0 ? "PASS" : "FAIL");
         fails += bad != 0;
     }
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
