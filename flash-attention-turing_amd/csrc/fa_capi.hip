@@ -85,7 +85,7 @@ const char* fa_last_error(void) { return g_err; }
 #ifndef FA_SOURCE_DIGEST
 #define FA_SOURCE_DIGEST "unstamped"      // build.py passes the first 12 hex digits of the sha256 over kernel sources, headers and flags
 #endif
-const char* fa_build_info(void) { return "flash_attn_gfx950 abi=" FA_STR(FA_ABI_VERSION) " arch=gfx950 mfma=32x32x16 wave64 src=" FA_SOURCE_DIGEST " built " __DATE__; }
+const char* fa_build_info(void) { return "flash_attn_gfx950 abi=" FA_STR(FA_ABI_VERSION) " arch=gfx950 mfma=32x32x16+16x16x32 wave64 src=" FA_SOURCE_DIGEST " built " __DATE__; }
 
 double fa_fwd_flops(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t d, int32_t is_causal) {
     double pairs;
@@ -112,6 +112,7 @@ double fa_fwd_bytes(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, in
 }
 
 const char* fa_fwd_kernel_name(int32_t d) { return fa::fwd_kernel_name(d); }
+int32_t fa_set_fwd_kernel_policy(int32_t policy) { return fa::set_fwd_kernel_policy(policy); }
 
 int fa_device_clock_khz(int32_t device) {
     int khz = 0;

@@ -15,6 +15,10 @@
 #include <type_traits>
 #include <stdint.h>
 
+#ifndef FA_MFMA16_BUILTIN
+#define FA_MFMA16_BUILTIN 0
+#endif
+
 namespace fa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -55,6 +59,27 @@ struct LP<_Float16> {
     static FA_DEV void mfma_agpr(f32x16& acc, u32x4 a, u32x4 b) {
         asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     }
+    // D(16x16) = A(16x32) * B(32x16) + C: lane l holds A row / B, C column l & 15, k = 8 * (l >> 4) + j, C rows 4 * (l >> 4) + r (tools/probe_isa)
+    static FA_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    // The same, IN PLACE, from inline asm: hipcc does not tie the destination of a 4-pass MFMA to its C operand and allocated new
+    // registers for every result (one v_mov_b64 pair per MFMA, +60 registers of pressure, spills).  The caller owns the hazards the
+    // compiler cannot see: >= 5 independent MFMAs between two on the same accumulator, wait states before a VALU reads a result.
+    static FA_DEV void mfma16_acc(f32x4& acc, u32x4 a, u32x4 b) {
+#if FA_MFMA16_BUILTIN
+        acc = mfma16(a, b, acc);
+#else
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+    }
+    static FA_DEV void mfma16_zero(f32x4& acc, u32x4 a, u32x4 b) {      // acc = A * B (C = 0)
+#if FA_MFMA16_BUILTIN
+        acc = mfma16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
+#else
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+#endif
+    }
     // round-to-nearest-even pack (v_cvt_pk_f16_f32): the reference rounds P/dS/O with
     // cutlass NumericArrayConverter (utils.h:19-27), which is RN as well.
     static FA_DEV uint32_t pack2(float lo, float hi) {
@@ -71,6 +96,23 @@ struct LP<__bf16> {
     }
     static FA_DEV void mfma_agpr(f32x16& acc, u32x4 a, u32x4 b) {
         asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+    static FA_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static FA_DEV void mfma16_acc(f32x4& acc, u32x4 a, u32x4 b) {
+#if FA_MFMA16_BUILTIN
+        acc = mfma16(a, b, acc);
+#else
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+    }
+    static FA_DEV void mfma16_zero(f32x4& acc, u32x4 a, u32x4 b) {
+#if FA_MFMA16_BUILTIN
+        acc = mfma16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
+#else
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+#endif
     }
     static FA_DEV uint32_t pack2(float lo, float hi) {
         f32x2 x = {lo, hi};

@@ -27,6 +27,8 @@
 // (flash_fwd_kernel.h:720-728,767-771) without relying on a zero pre-fill of the outputs.
 // Earlier alternatives (one-barrier-per-tile baseline, 4-wave variant, single-stream software pipeline) and the
 // timing-only ablation switches were removed from the product in round 2; they are in the history at commit a1ce086.
+#include <atomic>
+
 #include "fa_device.hpp"
 #include "fa_params.hpp"
 
@@ -523,12 +525,44 @@ static hipError_t launch_pp_t(const FwdKernelParams& kp, uint32_t grid, hipStrea
     return hipGetLastError();
 }
 
-const char* fwd_kernel_name(int) { return "fa_fwd_pp_kernel"; }
+// D = 128 has a second forward kernel, fa_fwd_pp16.hip: the same two-group schedule re-tiled for v_mfma_f32_16x16x32 (64 MFMAs per tile
+// and wave instead of 32, the same LDS traffic).  The chip runs these kernels against its power cap; the 16x16x32 shape draws less per
+// FLOP (tools/powerbench: 1.98 vs 1.66 PFLOP/s on N(0,1) data) and the kernel runs at ~1.87 GHz instead of ~1.55, but it needs ~12 % more
+// cycles (twice the MFMA issue slots on the VALU port).  It wins 3-5 % where the cap binds - long launches - and loses 2-10 % on short ones
+// (profiles/r3_fwd_mfma16_ab.log), so the launcher picks by the number of (query, key) pairs a launch computes.
+// FA_FWD_MFMA16: the policy a process starts with, 0 = never, 1 = always, 2 = by size (default); fa_set_fwd_kernel_policy() changes it
+// (tests run the whole forward grid through either kernel; a deployment that knows its launches are short can pin the 32x32x16 one).
+#ifndef FA_FWD_MFMA16
+#define FA_FWD_MFMA16 2
+#endif
+static std::atomic<int> g_fwd_policy{FA_FWD_MFMA16};
+int set_fwd_kernel_policy(int policy) {
+    if (policy < 0 || policy > 2) return -1;
+    return g_fwd_policy.exchange(policy, std::memory_order_relaxed);
+}
+constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 29;             // b4 h32 s2048 non-causal
+constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 31;       // b4 h16 s8192 causal (visible pairs); under a causal mask the late waves of a workgroup
+                                                                     // idle while the early ones finish, the cap binds less, and the break-even moves up
+hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
+
+static bool use_mfma16(const FwdKernelParams& kp) {
+    const int policy = g_fwd_policy.load(std::memory_order_relaxed);
+    if (kp.d != 128 || policy == 0) return false;
+    if (policy == 1) return true;
+    // (packed sequences: the bound b * max_seqlen_q, NOT total_q - the optional hint must not change which kernel, hence which bits,
+    // a call gets: tests/test_fuzz_gpu.py compares the compact and the plain varlen grid bit for bit)
+    const int64_t pairs = (int64_t)kp.b * kp.seqlen_q * kp.seqlen_k * kp.h / (kp.is_causal ? 2 : 1);
+    return pairs >= (kp.is_causal ? kFwdMfma16MinPairsCausal : kFwdMfma16MinPairs);
+}
+
+// the kernel that serves the LARGE problems of a head dimension (what a profile of the BASELINE configurations shows)
+const char* fwd_kernel_name(int d) { return d == 128 && g_fwd_policy.load(std::memory_order_relaxed) != 0 ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
 
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
+    if (use_mfma16(kp)) return launch_fwd_pp16(kp, dtype, grid, stream);
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, grid, stream) : launch_pp_t<_Float16, 64>(kp, grid, stream);
     return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, grid, stream) : launch_pp_t<__bf16, 64>(kp, grid, stream);
 }

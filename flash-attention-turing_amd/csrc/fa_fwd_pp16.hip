@@ -1,0 +1,443 @@
+// fa_fwd_pp16.hip -- the forward kernel of fa_fwd_pp.hip (same workgroup shape, rings, LDS-DMA, two-group ping-pong, optimistic softmax,
+// x3-unrolled loop; read its header first) re-tiled for v_mfma_f32_16x16x32_{f16,bf16}.
+//
+// Why: under matrix load this chip is power-limited, and the limit depends on the MFMA shape - a chip-wide loop of 16x16x32 MFMAs on N(0,1)
+// operands sustains 1.98 PFLOP/s against 1.66 for 32x32x16 (half the accumulator traffic per FLOP), and still +12 % inside this kernel's
+// own mix of 4 VALU + 1 KiB of LDS reads per 32768 FLOP (tools/powerbench, profiles/r3_powerbench_mfma_variants.log).
+//
+// What changes against the 32x32x16 kernel (everything else is identical, including the LDS tile image and every byte the DMA moves):
+//   * a lane is (k-group g = lane >> 4, column n = lane & 15): it owns TWO query rows of its wave's 32 (n and n + 16) and, of every 16-key
+//     score block, the 4 keys of its group; one LDS fragment (K rows / transposed V) feeds two MFMAs, one per query column, so LDS bytes
+//     and VALU work per FLOP are unchanged;
+//   * S^T = K Q^T in 16 x 16 blocks [key block][query column], contraction in 4 steps of 32 d; O^T = V^T P^T in 16-d blocks, contraction in
+//     chunks of 32 keys: a lane's P values of key blocks 2c and 2c+1 ARE the 8 k-slots of chunk c (C layout -> B operand, no data movement);
+//   * row max / row sum span four lanes (v_permlane16_swap + v_permlane32_swap) instead of two;
+//   * two k-slot permutations (d chunks {0,3,1,2}, key sub-blocks {0,2,1,3}) keep the unchanged XOR-swizzled tile image bank-conflict free
+//     under the new access patterns.
+#include "fa_device.hpp"
+#include "fa_params.hpp"
+
+#include <type_traits>
+
+namespace fa {
+
+constexpr int kFwdThreads = 512;
+constexpr int kFwdBlockM = 256;
+constexpr float kPpDeferLog2 = 6.0f;
+#define FA_PP_MIN_WAVES(D, BN) 2
+
+template <typename T, int D, bool CAUSAL, int BN>
+__global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp16_kernel(const FwdKernelParams p) {
+    constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;      // QK^T k-steps of 32 d; 16-wide d blocks of O
+    constexpr int kFwdBlockN = BN, NKB = BN / 16, NC = BN / 32;               // keys per tile; 16-key score blocks / 32-key P.V chunks per tile
+    constexpr int TILEB = kFwdBlockN * ROWB;
+    constexpr int RING = 3;
+    constexpr int RINGB = 2 * RING * TILEB, STAGEB = kFwdBlockM * ROWB;     // D = 128: 96 KiB + 64 KiB = all 160 KiB of the CU
+    __shared__ __attribute__((aligned(16))) char smem_raw[RINGB + STAGEB];
+    FA_LDS char* smem = (FA_LDS char*)smem_raw;
+    FA_LDS char* kring = smem;
+    FA_LDS char* vring = smem + RING * TILEB;
+    FA_LDS char* stage = smem + RINGB;            // O block on its way out; every wave touches only its own 32 rows
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, n16 = lane & 15;      // lane = (k-group g, column / row n16) of a 16x16x32 fragment
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2;
+    // k-slot permutations that keep the UNCHANGED LDS tile image (fa_device.hpp:lds_tile_off) bank-conflict free under the access patterns
+    // of 16x16x32 fragments (checked exhaustively against the service groups of ds_read_b128 / ds_read_b64_tr_b16):
+    //   d chunks:  lane group g contracts over d = 32*ks + 8*kPi[g] + 0..7          (A = K rows from LDS, B = Q^T from HBM: same permutation)
+    //   keys:      row i = 4*gi + r of score block kb is key 16*kb + 4*kPi2[gi] + r   (A = K row i; C rows 4*g + r; P.V k-slots; V^T tr reads)
+    const int pi_g = (0x2130 >> (4 * g)) & 3;             // kPi  = {0, 3, 1, 2}
+    const int pi2_g = (0x3120 >> (4 * g)) & 3;            // kPi2 = {0, 2, 1, 3}
+    const int q_row_a = wave * 32 + n16;                  // this lane's two query rows inside the 256-row block: q_row_a, q_row_a + 16
+    const float c = p.scale_log2e;
+    const uint32_t q_rowb = (uint32_t)(p.q.row * 2), k_rowb = (uint32_t)(p.k.row * 2),
+                   v_rowb = (uint32_t)(p.v.row * 2), o_rowb = (uint32_t)(p.o.row * 2);
+
+    // ---- items of this workgroup ------------------------------------------------------------------------
+    int tile, batch, head, tiles_seq;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (CAUSAL) tile = tiles_seq - 1 - tile;            // heaviest (latest) query tiles first
+
+    // ---- geometry (wave-uniform) -----------------------------------------------------------------------
+    int sq = p.seqlen_q, sk = p.seqlen_k;
+    int64_t q_row0 = 0, k_row0 = 0;
+    const bool varlen = p.cu_seqlens_q != nullptr;
+    if (varlen) {
+        const int q_beg = p.cu_seqlens_q[batch], k_beg = p.cu_seqlens_k[batch];
+        // a sequence longer than the declared max_seqlen_q is clamped: the padded LSE row holds max_seqlen_q entries only
+        sq = min(p.cu_seqlens_q[batch + 1] - q_beg, p.seqlen_q);
+        sk = p.cu_seqlens_k[batch + 1] - k_beg;
+        q_row0 = q_beg; k_row0 = k_beg;
+    }
+    if (tile * kFwdBlockM >= sq) return;
+    // row 0 of this (batch, head) in Q / O / LSE: everything an item needs beyond these is its tile index
+    const char* q_bh = (const char*)uniform_ptr((const T*)p.q_ptr + (varlen ? 0 : (int64_t)batch * p.q.batch) + q_row0 * p.q.row + (int64_t)head * p.q.head);
+    char* o_bh = (char*)uniform_ptr((T*)p.o_ptr + (varlen ? 0 : (int64_t)batch * p.o.batch) + q_row0 * p.o.row + (int64_t)head * p.o.head);
+    float* lse_bh = uniform_ptr(p.lse_ptr + ((int64_t)batch * p.h + head) * p.lse_row_stride);
+    const int head_k = head / p.h_ratio;
+    const srd_t k_srd = make_srd(uniform_ptr((const T*)p.k_ptr + (varlen ? 0 : (int64_t)batch * p.k.batch) + k_row0 * p.k.row + (int64_t)head_k * p.k.head),
+                                 sk > 0 ? (uint32_t)(sk - 1) * k_rowb + ROWB : 0u);
+    const srd_t v_srd = make_srd(uniform_ptr((const T*)p.v_ptr + (varlen ? 0 : (int64_t)batch * p.v.batch) + k_row0 * p.v.row + (int64_t)head_k * p.v.head),
+                                 sk > 0 ? (uint32_t)(sk - 1) * v_rowb + ROWB : 0u);
+    auto q_ptr_of = [&](int t) __attribute__((always_inline)) { return (const T*)(q_bh + (uint32_t)(t * kFwdBlockM) * q_rowb); };
+    auto o_ptr_of = [&](int t) __attribute__((always_inline)) { return (T*)(o_bh + (uint32_t)(t * kFwdBlockM) * o_rowb); };
+    auto rows_of = [&](int t) __attribute__((always_inline)) { return min(kFwdBlockM, sq - t * kFwdBlockM); };
+    int m0 = 0, delta = 0, n_tiles = 0, n_main = 0;   // of the CURRENT item
+    auto set_current = [&](int t) __attribute__((always_inline)) {
+        m0 = t * kFwdBlockM;
+        delta = sk - sq;
+        n_tiles = (sk + kFwdBlockN - 1) / kFwdBlockN;
+        if (CAUSAL) {
+            const int max_key = m0 + rows_of(t) - 1 + delta;
+            n_tiles = max_key < 0 ? 0 : min(n_tiles, max_key / kFwdBlockN + 1);
+        }
+        // Tiles [0, n_main) are fully visible to every row of the workgroup and fully inside the sequence: no mask, no per-wave
+        // skipping -> a branch-free steady-state loop.  The remaining (diagonal / ragged) tiles go through the generic body.
+        n_main = min(n_tiles, sk / kFwdBlockN);
+        if (CAUSAL) n_main = min(n_main, max(0, (m0 + delta + 1) / kFwdBlockN));
+    };
+
+    // ---- lane constants --------------------------------------------------------------------------------
+    // LDS-DMA staging: the tile image in LDS is lane-linear per wave instruction (1 KiB = 64 lanes x 16 B), so wave w moves
+    // the DPW 1-KiB pieces [w*DPW, (w+1)*DPW) of every K / V tile and the XOR swizzle is applied to the per-lane SOURCE offset.
+    // Every LDS-DMA of this kernel is issued from inline asm (fa_device.hpp:dma16_to_lds_hidden): hipcc never sees one, so it never
+    // parks a vmcnt(0) in front of an LDS read; completion is the explicit vmcnt(0) that ends every softmax phase.
+    constexpr int DPW = BN * SLOTS / 512;     // DMA instructions (1 KiB pieces) per wave per tile: 2 (1 for D = 64 with 64-key tiles)
+    uint32_t dma_goff_k[DPW], dma_goff_v[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int chunk = (wave * DPW + i) * 64 + lane;          // physical 16-byte chunk inside the tile
+        const int row = chunk / SLOTS, phys = chunk % SLOTS;
+        const int slot = lds_tile_logical_slot<D>(row, phys);
+        dma_goff_k[i] = row * k_rowb + slot * 16;
+        dma_goff_v[i] = row * v_rowb + slot * 16;
+    }
+    const uint32_t dma_loff = (uint32_t)wave * DPW * 1024;       // wave-uniform LDS offset of this wave's pieces
+    const uint32_t lds_k0 = lds_addr(kring) + dma_loff, lds_v0 = lds_addr(vring) + dma_loff;
+    // K row reads (A of S^T = K Q^T): key block kb, k-step ks -> row 16*kb + 4*kPi2[gi] + r (i = n16 = 4*gi + r), 16-byte slot 4*ks + kPi[g]
+    uint32_t k_rd[KS];
+    {
+        const int row = 4 * ((0x3120 >> (4 * (n16 >> 2))) & 3) + (n16 & 3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_rd[ks] = lds_addr(kring) + lds_tile_off<D>(row, 4 * ks + pi_g);
+    }
+    // V^T transposed reads (A of O^T += V^T P^T): 16-lane group g points at the 4 key rows 4*kPi2[g] .. +3 of a 16-key block, 16 d wide
+    uint32_t v_rd[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) v_rd[db] = lds_addr(vring) + lds_tile_off<D>(4 * pi2_g + (n16 >> 2), 2 * db + ((n16 & 3) >> 1)) + 8 * (n16 & 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(k_rd[ks]));      // (opaque: every fragment read is base register + immediate)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(v_rd[db]));
+
+    set_current(tile);
+
+    // Q^T fragments (B operand), two query columns per lane: qf[ks][qb] = Q[q_row_a + 16*qb][32*ks + 8*kPi[g] .. +7]
+    u32x4 qf[KS][2];
+    {
+        const rsrc_t q_rs = make_rsrc(uniform_ptr(q_ptr_of(tile)), (uint32_t)(rows_of(tile) - 1) * q_rowb + ROWB);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)(q_row_a + 16 * qb) * q_rowb + (4 * ks + pi_g) * 16);
+    }
+
+    f32x4 oacc[DB][2];                                    // O^T: d rows 16*db + 4*g + r, query column qb
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {kNegBig, kNegBig}, l_run[2] = {0.f, 0.f};      // per query column; l_run is this lane's PARTIAL row sum (its 4 of every 16 keys)
+
+    int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
+    auto dma_k_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * k_rowb + dma_goff_k[i], lds_k0 + slot * TILEB + i * 1024);
+    };
+    auto dma_v_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
+    };
+
+    // ---- prologue: K(0), V(0), K(1) into the rings (past-the-end tiles arrive as zeros) ---------------
+    if (n_tiles > 0) {
+        dma_k_tile(k_srd, 0, 0);
+        dma_v_tile(v_srd, 0, 0);
+        dma_k_tile(k_srd, 1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (group == 1) __syncthreads();          // group B runs one phase behind group A, for the whole life of the workgroup
+
+    f32x4 sacc[NKB][2];                               // S^T: key rows 4*g + r of score block kb (= keys 16*kb + 4*kPi2[g] + r), query column qb
+    u32x4 pf[NC][2];                                  // P^T as B operand of chunk c: k-slots = the lane's 4 keys of block 2c, then of block 2c+1
+    const int wave_q_lo = m0 + wave * 32, wave_q_hi = wave_q_lo + 31;
+
+    // One matrix phase = NPV P.V fragments (V(u-1)) + NQK QK^T fragments (K(u)); every fragment feeds TWO MFMAs (the lane's two query columns),
+    // so LDS bytes per FLOP are those of the 32x32x16 kernel.  Fragment j + PF is requested before the MFMAs of fragment j.
+    constexpr int NPV = NC * DB, NQK = NKB * KS, NST = NPV + NQK, PF = 4;
+    auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
+        if (j < NPV) {
+            const int db = j % DB, cch = j / DB;
+            const u32x2 a0 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_rd[db], slot_v * TILEB + (32 * cch) * ROWB);
+            const u32x2 a1 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_rd[db], slot_v * TILEB + (32 * cch + 16) * ROWB);
+            return u32x4{a0.x, a0.y, a1.x, a1.y};
+        }
+        const int i = j - NPV, ks = i / NKB, kb = i % NKB;
+        return lds_read16((const FA_LDS char*)(uintptr_t)k_rd[ks], slot_k * TILEB + 16 * kb * ROWB);
+    };
+    auto m_mfma = [&](auto jc, const u32x4& fr) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < NPV) {
+            constexpr int db = j % DB, cch = j / DB;
+            LP<T>::mfma16_acc(oacc[db][0], fr, pf[cch][0]);          // (this accumulator's previous MFMA is DB fragments = 2 * DB MFMAs back)
+            LP<T>::mfma16_acc(oacc[db][1], fr, pf[cch][1]);
+        } else {
+            constexpr int i = j - NPV, ks = i / NKB, kb = i % NKB;
+            if constexpr (ks == 0) {                               // (previous MFMA on this accumulator: NKB fragments back)
+                LP<T>::mfma16_zero(sacc[kb][0], fr, qf[ks][0]);
+                LP<T>::mfma16_zero(sacc[kb][1], fr, qf[ks][1]);
+            } else {
+                LP<T>::mfma16_acc(sacc[kb][0], fr, qf[ks][0]);
+                LP<T>::mfma16_acc(sacc[kb][1], fr, qf[ks][1]);
+            }
+        }
+    };
+    u32x4 pre[PF];
+    // full phase (P.V of the previous tile + QK^T of this one), ring slots as given (compile-time constants in the unrolled loop)
+    auto m_phase = [&](int slot_v, int slot_k) __attribute__((always_inline)) {
+        u32x4 fr[NST];
+        static_for<0, PF>([&](auto jc) { fr[decltype(jc)::value] = pre[decltype(jc)::value]; });
+        static_for<0, NST>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + PF < NST) fr[j + PF] = m_frag(j + PF, slot_v, slot_k);
+            __builtin_amdgcn_sched_barrier(0);
+            m_mfma(jc, fr[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto m_prefetch = [&](int slot_v, int slot_k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) pre[j] = m_frag(j, slot_v, slot_k);
+    };
+    // un-pipelined halves for the first / diagonal / last tiles
+    auto pv_step = [&]() __attribute__((always_inline)) {
+        static_for<0, NPV>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u)); });
+    };
+    auto qk_step = [&]() __attribute__((always_inline)) {
+        static_for<NPV, NST>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u)); });
+    };
+    auto issue_dma_k = [&](int u) __attribute__((always_inline)) {
+        if (u + 2 < n_tiles) dma_k_tile(k_srd, u + 2, ring_um1);
+    };
+    auto issue_dma_v = [&](int u) __attribute__((always_inline)) {
+        if (u + 1 < n_tiles) dma_v_tile(v_srd, u + 1, ring_up1);
+    };
+    // max / sum over the four lane groups that share a query column (lanes l, l ^ 16, l ^ 32, l ^ 48)
+    auto max4 = [&](float x) __attribute__((always_inline)) -> float {
+        uint32_t u = __builtin_bit_cast(uint32_t, x);
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        x = fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+        return max_both_halves(x);
+    };
+    auto sum4 = [&](float x) __attribute__((always_inline)) -> float {
+        uint32_t u = __builtin_bit_cast(uint32_t, x);
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        x = __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+        return sum_both_halves(x);
+    };
+    auto softmax_step = [&](int u, auto masked, auto maybe_first) __attribute__((always_inline)) {
+        // the scores were written by MFMAs issued from inline asm, which the hazard recogniser does not see: a 4-pass XDL write needs its
+        // wait states before a VALU reads it (the barrier and the DMA issue in between usually cover them; this makes it unconditional)
+        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+        const int n0 = u * kFwdBlockN;
+        if constexpr (decltype(masked)::value) {
+            const bool need_mask = (n0 + kFwdBlockN > sk) || (CAUSAL && (n0 + kFwdBlockN - 1 > wave_q_lo + delta));
+            if (need_mask) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int lim = (CAUSAL ? min(sk - 1, m0 + q_row_a + 16 * qb + delta) : sk - 1) - n0 - 4 * pi2_g;     // key = n0 + 16*kb + 4*kPi2[g] + r
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kb][qb][r] = (16 * kb + r) <= lim ? sacc[kb][qb][r] : -INFINITY;
+                }
+            }
+        }
+        // One exponentiation pass against the running max AS IT STANDS (no row-max reduction): it stands if no lane's partial row sum exceeds
+        // 2^kPpDeferLog2 - then no term does, and P, l and O stay in range.  Otherwise (Inf / NaN included; always on the first tile, whose
+        // running max is still -1e30) the wave reduces the row maxima; if some row outgrew its running max by more than 2^kPpDeferLog2 the max is
+        // refreshed, l and O are rescaled and the SAME pass runs once more (now every term is <= 1); if not, the pass already holds exactly
+        // what the exact path would compute.
+        // Tile 0 meets an empty running max: its first pass would always be thrown away, so the running max is seeded with the tile's row
+        // maxima (no O or l to rescale yet) and the pass below stands at once.
+        if constexpr (decltype(maybe_first)::value) {
+            if (u == 0) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float mx = sacc[0][qb][0];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kb][qb][r]);
+                    m_run[qb] = fmaxf(kNegBig, max4(mx));
+                }
+            }
+        }
+        float ps[2];
+        for (int attempt = 0;; ++attempt) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float mc0 = m_run[qb] * c;
+                ps[qb] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const float p0 = fast_exp2(__builtin_fmaf(sacc[kb][qb][0], c, -mc0)), p1 = fast_exp2(__builtin_fmaf(sacc[kb][qb][1], c, -mc0));
+                    const float p2 = fast_exp2(__builtin_fmaf(sacc[kb][qb][2], c, -mc0)), p3 = fast_exp2(__builtin_fmaf(sacc[kb][qb][3], c, -mc0));
+                    ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3;
+                    if (kb & 1) { pf[kb >> 1][qb].z = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].w = LP<T>::pack2(p2, p3); }
+                    else { pf[kb >> 1][qb].x = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].y = LP<T>::pack2(p2, p3); }
+                }
+            }
+#if FA_PP16_PIN_PF
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) { asm volatile("" : "+v"(pf[cc][0])); asm volatile("" : "+v"(pf[cc][1])); }
+#endif
+            if (attempt != 0 || __builtin_amdgcn_ballot_w64(!(ps[0] <= 64.0f && ps[1] <= 64.0f)) == 0) break;
+            float mx[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                mx[qb] = sacc[0][qb][0];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx[qb] = fmaxf(mx[qb], sacc[kb][qb][r]);
+                mx[qb] = max4(mx[qb]);
+            }
+            // (one decision for both query columns: refreshing a column that did not need it is exact too)
+            if (__builtin_amdgcn_ballot_w64((mx[0] - m_run[0]) * c > kPpDeferLog2 || (mx[1] - m_run[1]) * c > kPpDeferLog2) == 0) break;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float m_new = fmaxf(m_run[qb], mx[qb]);
+                const float alpha = fast_exp2((m_run[qb] - m_new) * c);
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[db][qb][r] *= alpha;
+            }
+        }
+        l_run[0] += ps[0];
+        l_run[1] += ps[1];
+    };
+    auto advance_ring = [&]() __attribute__((always_inline)) {
+        ring_um1 = ring_u;
+        ring_u = ring_up1;
+        ring_up1 = ring_up1 == 2 ? 0 : ring_up1 + 1;
+    };
+    auto end_s_phase = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // Epilogue, wave-local: normalise, round, stage this wave's 32 rows in LDS (own region), store them as whole rows.
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");        // (asm-issued MFMAs: results must have landed before the VALU below reads them)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { asm volatile("" : "+v"(oacc[db][0])); asm volatile("" : "+v"(oacc[db][1])); }
+        const int rows_here = rows_of(t);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float l_tot = sum4(l_run[qb]);
+            // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
+            const float inv = l_tot != 0.f ? fast_rcp(l_tot) : 0.f;
+            const float lse = l_tot != 0.f ? (m_run[qb] * c + fast_log2(l_tot)) * kLn2 : 0.f;
+            const int row = q_row_a + 16 * qb;
+            if (g == 0 && row < rows_here) lse_bh[t * kFwdBlockM + row] = lse;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                u32x2 w;
+                w.x = LP<T>::pack2(oacc[db][qb][0] * inv, oacc[db][qb][1] * inv);
+                w.y = LP<T>::pack2(oacc[db][qb][2] * inv, oacc[db][qb][3] * inv);
+                lds_write8(stage, lds_tile_off<D>(row, 2 * db + (g >> 1)) + 8 * (g & 1), w);      // d = 16*db + 4*g + {0..3}
+            }
+        }
+        const rsrc_t o_rs = make_rsrc(uniform_ptr(o_ptr_of(t)), (uint32_t)(rows_here - 1) * o_rowb + ROWB);
+        constexpr int O_CHUNKS = (32 * SLOTS) / 64;
+#pragma unroll
+        for (int i = 0; i < O_CHUNKS; ++i) {
+            const int chunk = lane + i * 64, row = wave * 32 + chunk / SLOTS, slot = chunk % SLOTS;
+            buf_store16(o_rs, (uint32_t)row * o_rowb + slot * 16, lds_read16(stage, lds_tile_off<D>(row, slot)));   // rows >= rows_here fall outside the SRD
+        }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    bool prev_active = false;                         // does this wave hold a P tile whose P.V is pending?
+    auto iteration = [&](int u, auto masked) __attribute__((always_inline)) {
+        bool active = true;
+        if constexpr (decltype(masked)::value) active = !CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta);
+        if (prev_active) pv_step();
+        if (active) qk_step();
+        issue_dma_k(u);
+        __syncthreads();
+        issue_dma_v(u);
+        if (active) softmax_step(u, masked, yes{});
+        prev_active = active;
+        end_s_phase();
+        advance_ring();
+    };
+
+    int u = 0;
+    if (n_main > 0) {
+        iteration(0, no{});
+        if (n_main > 1) m_prefetch(ring_um1, ring_u);
+        auto step_c = [&](int uu, auto um1, auto u0, auto up1) __attribute__((always_inline)) {
+            constexpr int S_UM1 = decltype(um1)::value, S_U = decltype(u0)::value, S_UP1 = decltype(up1)::value;
+            m_phase(S_UM1, S_U);
+            __syncthreads();
+            if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
+            if (uu + 1 < n_tiles) dma_v_tile(v_srd, uu + 1, S_UP1);
+            softmax_step(uu, no{}, no{});
+            m_prefetch(S_U, S_UP1);
+            end_s_phase();
+        };
+        using i0 = std::integral_constant<int, 0>;
+        using i1 = std::integral_constant<int, 1>;
+        using i2 = std::integral_constant<int, 2>;
+        u = 1;
+        for (; u + 3 <= n_main; u += 3) {         // ring slot of tile u is u % 3: three steps per trip make every slot a constant
+            step_c(u, i0{}, i1{}, i2{});
+            step_c(u + 1, i1{}, i2{}, i0{});
+            step_c(u + 2, i2{}, i0{}, i1{});
+        }
+        for (; u < n_main; ++u) {                 // the last one or two steady-state tiles
+            m_phase(ring_um1, ring_u);
+            __syncthreads();
+            issue_dma_k(u);
+            issue_dma_v(u);
+            softmax_step(u, no{}, no{});
+            m_prefetch(ring_u, ring_up1);
+            end_s_phase();
+            advance_ring();
+        }
+    }
+    for (; u < n_tiles; ++u) iteration(u, yes{});        // diagonal / ragged tiles
+    if (prev_active) pv_step();
+    epilogue(tile);
+    if (group == 0) __syncthreads();          // group A waits for B's last phase (equal barrier counts)
+}
+
+hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream) {
+    if (grid == 0) return hipSuccess;
+    if (dtype == 0) {
+        if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, true, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        else hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, false, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    } else {
+        if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 128, true, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        else hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 128, false, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fa

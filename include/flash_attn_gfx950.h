@@ -200,9 +200,19 @@ int64_t fa_bwd_workspace_bytes(const fa_bwd_params* params);
 double fa_fwd_flops(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal);
 /* Algorithmic HBM bytes of one forward call: q,k,v,o once + lse. */
 double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d);
-/* Name of the forward kernel the library dispatches to for this head_dim (what a profiler's kernel trace will show; lets a
- * benchmark tie a committed PMC profile to the kernel that actually ran). */
+/* Name of the forward kernel the library dispatches LARGE problems of this head_dim to (what a profiler's kernel trace of the
+ * BASELINE configurations will show; lets a benchmark tie a committed PMC profile to the kernel that actually ran).  head_dim 128
+ * has two kernels: launches of fewer than 2^29 (query, key) pairs (2^31 visible pairs under a causal mask) run fa_fwd_pp_kernel,
+ * larger ones fa_fwd_pp16_kernel. */
 const char* fa_fwd_kernel_name(int32_t d);
+/* Which of the two head_dim-128 forward kernels serves a launch: FA_FWD_POLICY_BY_SIZE (the default) as described above,
+ * FA_FWD_POLICY_MFMA32 / FA_FWD_POLICY_MFMA16 pin one of them for every launch.  Both kernels meet the same tolerances; they differ in
+ * speed only (the 16x16x32 one draws less power per FLOP and wins where the chip's power cap binds).  Process-wide, thread-safe;
+ * returns the previous policy, -1 (and changes nothing) for an unknown value.  The reference has no counterpart. */
+#define FA_FWD_POLICY_MFMA32 0
+#define FA_FWD_POLICY_MFMA16 1
+#define FA_FWD_POLICY_BY_SIZE 2
+int32_t fa_set_fwd_kernel_policy(int32_t policy);
 /* Peak shader clock of `device` in kHz (hipDeviceAttributeClockRate), or a negative HIP error code: with 256 CUs x 4096 FLOP/clk/CU
  * it derives the dense fp16 MFMA peak a benchmark quotes (256 x 2.4 GHz x 4096 = 2.5 PFLOP/s). */
 int fa_device_clock_khz(int32_t device);

@@ -1,6 +1,7 @@
 """Compile a .hip file of the package to gfx950 assembly (hipcc cross-compiles without a GPU) and report, per kernel,
 the compiler's own resource usage (-Rpass-analysis=kernel-resource-usage) plus what sits INSIDE its MFMA loops:
 scratch (spill) traffic and v_accvgpr_* register shuffles.  Test infrastructure only."""
+import collections
 import os
 import re
 import subprocess
@@ -39,7 +40,7 @@ def analyse(hip_source, extra_flags=()):
     src = os.path.join(_build.CSRC, hip_source)
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
-        cmd = [_build.hipcc_path()] + list(_build.HIPCC_FLAGS) + list(extra_flags) + ["-I", _build.CSRC, "-I", _build.INCLUDE, "--cuda-device-only", "-S", src,
+        cmd = [_build.hipcc_path()] + list(_build.HIPCC_FLAGS) + list(_build.EXTRA_FLAGS.get(hip_source, [])) + list(extra_flags) + ["-I", _build.CSRC, "-I", _build.INCLUDE, "--cuda-device-only", "-S", src,
                                                                                       "-o", asm, "-Rpass-analysis=kernel-resource-usage"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -78,7 +79,8 @@ def analyse(hip_source, extra_flags=()):
                                       "accvgpr_moves": len(re.findall(r"v_accvgpr_(?:read|write|mov)", seg)),
                                       "valu": len([1 for x in re.findall(r"^\s+(v_[a-z0-9_]+)", seg, re.M) if "mfma" not in x]),
                                       "ds_read_b128": len(re.findall(r"ds_read_b128", seg)), "ds_read_tr": len(re.findall(r"ds_read_b64_tr", seg)),
-                                      "barriers": len(re.findall(r"s_barrier", seg))})
+                                      "barriers": len(re.findall(r"s_barrier", seg)),
+                                      "histogram": dict(collections.Counter(re.findall(r"^\s+([vs]_[a-z0-9_]+|ds_[a-z0-9_]+|buffer_[a-z0-9_]+)", seg, re.M)).most_common())})
     return kernels
 
 

@@ -17,6 +17,15 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.fa_build_info()
 
 
+def test_forward_kernel_policy_is_host_state():
+    """fa_set_fwd_kernel_policy: returns the previous value, refuses unknown ones, and fa_fwd_kernel_name follows it (no GPU involved)"""
+    assert capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA32) == capi.FWD_POLICY_BY_SIZE      # the library's initial policy
+    assert capi.fwd_kernel_name(128) == "fa_fwd_pp_kernel"
+    assert capi.lib().fa_set_fwd_kernel_policy(3) == -1 and capi.lib().fa_set_fwd_kernel_policy(-1) == -1
+    assert capi.set_fwd_kernel_policy(capi.FWD_POLICY_BY_SIZE) == capi.FWD_POLICY_MFMA32
+    assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel" and capi.fwd_kernel_name(64) == "fa_fwd_pp_kernel"
+
+
 def test_flops_and_bytes_match_survey_figures():
     L = capi.lib()
     # SURVEY.md §8(d): C2 1.0995e12, C3 non-causal 1.7592e13

@@ -1,0 +1,131 @@
+"""GPU: the second head_dim-128 forward kernel (fa_fwd_pp16.hip, v_mfma_f32_16x16x32 tiles).
+
+The launcher gives it the LARGE launches only (>= 2^29 (query, key) pairs, 2^31 under a causal mask: include/flash_attn_gfx950.h, fa_set_fwd_kernel_policy), so
+of the suite only the full-size value-parity and property tests reach it on their own.  This module pins the policy to that kernel
+and runs the forward-facing tests of the other modules again at head_dim 128: the golden vectors, the C-oracle cases, the
+reference's (sq, sk) grid, packed sequences, the softmax edge cases - every tail, mask and head-group path of the kernel.  It also
+pins the 32x32x16 kernel at the BASELINE sizes the policy would give to the other one, so both kernels are value-checked at both ends.
+The backward halves of those tests run too (on this kernel's O and LSE)."""
+import numpy as np
+import pytest
+import torch
+
+import _util as U
+import test_attention_gpu as TA
+import test_properties_gpu as TP
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def pin_mfma16(gpu):
+    from flash_attn_turing import capi
+
+    prev = capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA16)
+    assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel"
+    yield
+    capi.set_fwd_kernel_policy(prev)
+
+
+def _d128_golden():
+    return [n for n in U.golden_names() if U.load_golden(n)["q"].shape[-1] == 128]
+
+
+@pytest.mark.parametrize("name", _d128_golden())
+def test_golden_vectors(gpu, name):
+    TA.test_golden_vectors(gpu, name)
+
+
+@pytest.mark.parametrize("b,sq,sk,h,hk,d,causal,dtype", [c for c in TA.ORACLE_CASES if c[5] == 128])
+def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype):
+    TA.test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("batch_size", [1, 3])
+@pytest.mark.parametrize("nheads,nheads_k", [(2, 1), (6, 3), (6, 1), (4, 4)])
+def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, causal):
+    TA.test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, 128, causal)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("nheads,nheads_k", [(4, 2), (6, 1), (2, 2)])
+def test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, causal):
+    TA.test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, 128, causal)
+
+
+def test_online_softmax_rescale_spike(gpu):
+    TA.test_online_softmax_rescale_spike(gpu)
+
+
+def test_bf16_backward_medium(gpu):
+    TA.test_bf16_backward_medium(gpu)
+
+
+def test_causal_first_rows_copy_v(gpu):
+    TP.test_causal_first_rows_copy_v(gpu)
+
+
+def test_empty_and_degenerate_shapes(gpu):
+    TP.test_empty_and_degenerate_shapes(gpu)
+
+
+def test_large_magnitude_inputs_stay_finite(gpu):
+    TP.test_large_magnitude_inputs_stay_finite(gpu)
+
+
+def test_nonfinite_scores_propagate_like_fp32_math(gpu):
+    TP.test_nonfinite_scores_propagate_like_fp32_math(gpu)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_identity_inputs_analytic_known_answer(gpu, causal):
+    TP.test_identity_inputs_analytic_known_answer(gpu, 128, causal)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("ramp", [1.0, 0.02, -1.0])
+def test_running_max_rising_along_the_key_axis(gpu, dtype, ramp):
+    TP.test_running_max_rising_along_the_key_axis(gpu, 128, dtype, ramp)
+
+
+def test_launch_path_is_hip_graph_capturable(gpu):
+    TP.test_launch_path_is_hip_graph_capturable(gpu)
+
+
+def test_policy_switches_kernels_and_both_agree(gpu):
+    """the same problem through both kernels: equal within two roundings of the output format (they sum the same products in a
+    different order), LSE to 1e-5; an unknown policy is refused and changes nothing"""
+    import flash_attn_turing as F
+    from flash_attn_turing import capi
+
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    q, k, v = (torch.randn(2, 777, 4, 128, device=gpu, dtype=torch.float16, generator=gen) for _ in range(3))
+    outs = {}
+    for pol in (capi.FWD_POLICY_MFMA32, capi.FWD_POLICY_MFMA16, capi.FWD_POLICY_BY_SIZE):
+        capi.set_fwd_kernel_policy(pol)
+        o, lse = F.fwd(q, k, v, True)
+        torch.cuda.synchronize()
+        outs[pol] = (o.float(), lse)
+    assert torch.equal(outs[capi.FWD_POLICY_BY_SIZE][0], outs[capi.FWD_POLICY_MFMA32][0])          # a small launch: the 32x32x16 kernel
+    assert not torch.equal(outs[capi.FWD_POLICY_MFMA16][0], outs[capi.FWD_POLICY_MFMA32][0])       # (different summation order)
+    assert (outs[capi.FWD_POLICY_MFMA16][0] - outs[capi.FWD_POLICY_MFMA32][0]).abs().max().item() <= 2e-3
+    assert (outs[capi.FWD_POLICY_MFMA16][1] - outs[capi.FWD_POLICY_MFMA32][1]).abs().max().item() <= 1e-5
+    with pytest.raises(ValueError):
+        capi.set_fwd_kernel_policy(7)
+    assert capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA16) == capi.FWD_POLICY_BY_SIZE
+
+
+@pytest.mark.parametrize("name", ["c2_fwd_4k", "c3_fwd_16k_causal"])
+def test_mfma32_kernel_values_at_baseline_sizes(gpu, name):
+    """the policy gives these sizes to the 16x16x32 kernel (tests/test_value_parity_gpu.py checks it there); the 32x32x16 kernel must
+    stay value-correct at them too - it serves them under FA_FWD_POLICY_MFMA32"""
+    import test_value_parity_gpu as TV
+    from flash_attn_turing import capi
+
+    capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA32)
+    TV._cache.clear()
+    try:
+        TV.test_forward_values_row_blocks_vs_c_oracle(gpu, name)
+    finally:
+        TV._cache.clear()

@@ -8,7 +8,7 @@ import pytest
 
 from _kernel_isa import analyse
 
-FILES = ["fa_fwd_pp.hip", "fa_bwd.hip"]
+FILES = ["fa_fwd_pp.hip", "fa_fwd_pp16.hip", "fa_bwd.hip"]
 # whole-kernel scratch that is known, outside every loop (prologue / epilogue), and bounded here so growth is noticed
 SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 112, "fa_bwd_dq_kernel": 64}      # dK/dV: D = 64 causal carries 100 B since the second (workspace) epilogue
 # scratch ops INSIDE an MFMA loop: zero everywhere since round 3 (rounds 1-2 allowed the two D = 64 backward kernels, squeezed to 128
@@ -54,7 +54,7 @@ def test_whole_kernel_scratch_is_zero_or_on_the_allow_list(kernels):
 
 def test_two_waves_per_simd_for_the_eight_wave_kernels(kernels):
     for (f, name), info in kernels.items():
-        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel")):
+        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_fwd_pp16_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel")):
             assert info["occupancy"] >= 2, (f, name, info["occupancy"])
 
 
@@ -79,10 +79,26 @@ def test_forward_kernels_touch_m0_only_in_their_own_lds_dma_statements(kernels):
     nothing hipcc generates for those kernels reads or writes M0 (no compiler-visible LDS-DMA, no indirect register indexing)"""
     seen = 0
     for (f, name), info in kernels.items():
-        if "fa_fwd_pp_kernel" in name:
+        if "fa_fwd_pp_kernel" in name or "fa_fwd_pp16_kernel" in name:
             seen += 1
             assert info["m0_outside_asm"] == 0, (name, info["m0_outside_asm"])
-    assert seen >= 8
+    assert seen >= 12
+
+
+def test_mfma16_forward_keeps_its_accumulators_in_place(kernels):
+    """fa_fwd_pp16: hipcc does not tie a 4-pass MFMA's destination to its C operand, and a conditional rescale of the 64 O registers that
+    merges back into the hot path made it copy half of them per tile (16 v_mov_b64 + 19 v_mov_b32, +44 % VALU instructions, 5 % slower
+    than the 32x32x16 kernel instead of 5 % faster: profiles/r3_fwd_mfma16_ab.log); with the SLP vectoriser on, it spills as well.  The
+    steady-state loop must hold no 64-bit register copy and only the handful of v_mov_b32 the cross-lane max needs."""
+    seen = 0
+    for (f, name), info in kernels.items():
+        if "fa_fwd_pp16_kernel" in name:
+            seen += 1
+            main = max(info["loops"], key=lambda l: l["mfma"])
+            assert main["mfma"] == 192, (name, main["mfma"])                          # three tiles of 64
+            assert main["histogram"].get("v_mov_b64_e32", 0) == 0, (name, main["histogram"])
+            assert main["histogram"].get("v_mov_b32_e32", 0) <= 24, (name, main["histogram"])
+    assert seen == 4
 
 
 def test_guard_detects_the_known_pathology():

@@ -61,7 +61,8 @@ def main():
     st4, f4 = stats(os.path.join(EV, "bench_c4_stats"))
     shutil.copy(f3, os.path.join(PROF, f"{TAG}_bench_kernel_stats.csv"))
     shutil.copy(f4, os.path.join(PROF, f"{TAG}_bench_c4_kernel_stats.csv"))
-    fwd = st3["fa_fwd_pp_kernel"]
+    fwd_name = b["roofline"]["kernel"]                       # the kernel bench.py timed (fa_fwd_kernel_name)
+    fwd = st3[fwd_name]
     flops = b["roofline"]["algorithmic_flops_per_launch"]
     frac_prof = flops / (fwd["avg_ns"] * 1e-9) / 1e12 / b["roofline"]["peak"]
     # HBM traffic (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md, WRITE_SIZE as is; first launch of each kernel skipped)
@@ -72,9 +73,9 @@ def main():
             if k.startswith("fa_"):
                 rd, w = fe[k]["mean"] * 1024 * 2, wr.get(k, {"mean": 0.0})["mean"] * 1024
                 hbm[f"{tag}:{k}"] = {"read_bytes_corrected": rd, "write_bytes": w, "traffic_bytes_per_launch": rd + w, "launches_profiled": fe[k]["launches"]}
-    f = hbm["fwd_c3:fa_fwd_pp_kernel"]
+    f = hbm["fwd_c3:" + fwd_name]
     with open(os.path.join(PROF, f"{TAG}_hbm_traffic.json"), "w") as fo:
-        json.dump({"workload": "c3", "kernel": "fa_fwd_pp_kernel", "traffic_bytes_per_launch": f["traffic_bytes_per_launch"],
+        json.dump({"workload": "c3", "kernel": fwd_name, "traffic_bytes_per_launch": f["traffic_bytes_per_launch"],
                    "read_bytes_corrected": f["read_bytes_corrected"], "write_bytes": f["write_bytes"],
                    "algorithmic_bytes_per_launch": 2155872256, **tagline,
                    "source": "tools/round_evidence.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per "

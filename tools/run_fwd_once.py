@@ -18,7 +18,10 @@ ap.add_argument("--causal", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--bwd", type=int, default=0)
 ap.add_argument("--dtype", default="fp16")
+ap.add_argument("--lib", default=None, help="an A/B build from tools/build_variant.py instead of the in-tree library")
 a = ap.parse_args()
+if a.lib:
+    capi.LIBRARY_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda:0")
 dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 gen = torch.Generator(device=dev).manual_seed(1)
