@@ -747,13 +747,20 @@ static hipError_t launch_dq_t(const BwdKernelParams& kp, hipStream_t s) {
     else hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, false>), dim3(grid), dim3(kDqThreads), 0, s, kp);
     return hipGetLastError();
 }
+hipError_t launch_bwd_dkdv16(const BwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t s);      // fa_bwd_dkdv16.hip (head_dim 128, v_mfma_f32_16x16x32)
+static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv);                                      // (below, next to the launchers)
 template <typename T, int D>
 static hipError_t launch_dkdv_t(const BwdKernelParams& kp, hipStream_t s) {
     const uint32_t grid = (kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h_k : kp.n_k_tiles * (uint32_t)kp.b * (uint32_t)kp.h_k) * (uint32_t)kp.n_split;
     if (grid == 0) return hipSuccess;
-    if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-    else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (bwd_use_mfma16(kp, true)) {
+        e = launch_bwd_dkdv16(kp, std::is_same<T, _Float16>::value ? 0 : 1, grid, s);
+    } else {
+        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        else hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess || kp.n_split == 1) return e;
     const int64_t items = kp.ws_rows * kp.h_k * (D / 8);
     hipLaunchKernelGGL((fa_bwd_sum_splits_kernel<T, D>), dim3((uint32_t)((items + kSumThreads - 1) / kSumThreads)), dim3(kSumThreads), 0, s, kp);
@@ -769,9 +776,24 @@ hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDotRowsPerBlock, tiles) : 0u;
     return FA_DISPATCH(launch_dot_t, kp, dtype, s);
 }
+// head_dim 128 has a second set of kernels, re-tiled for v_mfma_f32_16x16x32 (fa_bwd_dq16.hip, fa_bwd_dkdv16.hip; why: fa_fwd_pp16.hip).
+// Measured against the kernels of this file (profiles/r3_bwd_mfma16_ab.log, three boxes): dQ -1..-6 % without a mask at every length but
+// +1..+4 % under a causal mask; dK/dV -2..-5 % on long launches, +-2 % on short ones.  FA_POLICY_AUTO follows those signs; fa_set_kernel_policy()
+// pins either set.
+constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 31;       // (query, key) pairs a dK/dV launch computes: b4 h32 s8192 causal
+static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
+    const int policy = kernel_policy();
+    if (kp.d != 128 || policy == 0) return false;
+    if (policy == 1) return true;
+    if (!dkdv) return !kp.is_causal;
+    // (the bound b * max_seqlen, never total_q / total_k: the optional hints must not change which kernel, hence which bits, a call gets)
+    return (int64_t)kp.b * kp.seqlen_q * kp.seqlen_k * kp.h / (kp.is_causal ? 2 : 1) >= kKvMfma16MinPairs;
+}
+hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s);      // fa_bwd_dq16.hip (head_dim 128, v_mfma_f32_16x16x32)
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
+    if (bwd_use_mfma16(kp, false)) return launch_bwd_dq16(kp, dtype, s);
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
 #ifndef FA_KV_SPLIT_CAUSAL_PER_CU

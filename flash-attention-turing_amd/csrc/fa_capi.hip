@@ -112,7 +112,7 @@ double fa_fwd_bytes(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, in
 }
 
 const char* fa_fwd_kernel_name(int32_t d) { return fa::fwd_kernel_name(d); }
-int32_t fa_set_fwd_kernel_policy(int32_t policy) { return fa::set_fwd_kernel_policy(policy); }
+int32_t fa_set_kernel_policy(int32_t policy) { return fa::set_kernel_policy(policy); }
 
 int fa_device_clock_khz(int32_t device) {
     int khz = 0;

@@ -80,6 +80,10 @@ struct LP<_Float16> {
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 #endif
     }
+    // acc = A * B + C with C in its own registers (kept across calls): the forward's scores start from -running_max
+    static FA_DEV void mfma16_init(f32x4& acc, u32x4 a, u32x4 b, const f32x4& c) {
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+    }
     // round-to-nearest-even pack (v_cvt_pk_f16_f32): the reference rounds P/dS/O with
     // cutlass NumericArrayConverter (utils.h:19-27), which is RN as well.
     static FA_DEV uint32_t pack2(float lo, float hi) {
@@ -113,6 +117,10 @@ struct LP<__bf16> {
 #else
         asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 #endif
+    }
+    // acc = A * B + C with C in its own registers (kept across calls): the forward's scores start from -running_max
+    static FA_DEV void mfma16_init(f32x4& acc, u32x4 a, u32x4 b, const f32x4& c) {
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
     }
     static FA_DEV uint32_t pack2(float lo, float hi) {
         f32x2 x = {lo, hi};
@@ -254,6 +262,18 @@ FA_DEV float sum_both_halves(float x) {
     uint32_t u = __builtin_bit_cast(uint32_t, x);
     auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+
+// the same over the four 16-lane groups of a 16x16x32 fragment (lanes l, l ^ 16, l ^ 32, l ^ 48)
+FA_DEV float sum_four_groups(float x) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return sum_both_halves(__builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+FA_DEV float max_four_groups(float x) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return max_both_halves(fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1])));
 }
 
 FA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32

@@ -530,13 +530,14 @@ static hipError_t launch_pp_t(const FwdKernelParams& kp, uint32_t grid, hipStrea
 // FLOP (tools/powerbench: 1.98 vs 1.66 PFLOP/s on N(0,1) data) and the kernel runs at ~1.87 GHz instead of ~1.55, but it needs ~12 % more
 // cycles (twice the MFMA issue slots on the VALU port).  It wins 3-5 % where the cap binds - long launches - and loses 2-10 % on short ones
 // (profiles/r3_fwd_mfma16_ab.log), so the launcher picks by the number of (query, key) pairs a launch computes.
-// FA_FWD_MFMA16: the policy a process starts with, 0 = never, 1 = always, 2 = by size (default); fa_set_fwd_kernel_policy() changes it
+// FA_FWD_MFMA16: the policy a process starts with, 0 = never, 1 = always, 2 = by size (default); fa_set_kernel_policy() changes it
 // (tests run the whole forward grid through either kernel; a deployment that knows its launches are short can pin the 32x32x16 one).
 #ifndef FA_FWD_MFMA16
 #define FA_FWD_MFMA16 2
 #endif
 static std::atomic<int> g_fwd_policy{FA_FWD_MFMA16};
-int set_fwd_kernel_policy(int policy) {
+int kernel_policy() { return g_fwd_policy.load(std::memory_order_relaxed); }
+int set_kernel_policy(int policy) {
     if (policy < 0 || policy > 2) return -1;
     return g_fwd_policy.exchange(policy, std::memory_order_relaxed);
 }

@@ -25,6 +25,14 @@ constexpr int kFwdThreads = 512;
 constexpr int kFwdBlockM = 256;
 constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PP_MIN_WAVES(D, BN) 2
+// FA_PP16_FOLD_MAX = 1 (measured, NOT shipped): Q pre-scaled by log2(e)/sqrt(d) and rounded back to fp16 / bf16, every score block's MFMA
+// chain started from -running_max instead of 0, so that P = exp2(score) with no multiply-subtract per score (a quarter of the softmax
+// VALU work).  +5 % at the fp16 BASELINE shapes, nothing at bf16 - and the extra rounding of Q moves LSE by 2-5e-4 (fp16) / 2-5e-3 (bf16) on
+// N(0,1) inputs, 100x that on inputs 30x larger, where the exact kernels agree with fp32 math to 1e-6: the north star asks for LSE within
+// fp32 tolerance, so the exact form stays (profiles/r3_fwd_mfma16_ab.log).
+#ifndef FA_PP16_FOLD_MAX
+#define FA_PP16_FOLD_MAX 0
+#endif
 
 template <typename T, int D, bool CAUSAL, int BN>
 __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp16_kernel(const FwdKernelParams p) {
@@ -140,6 +148,18 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)(q_row_a + 16 * qb) * q_rowb + (4 * ks + pi_g) * 16);
+#if FA_PP16_FOLD_MAX
+        // Q' = round(Q * log2(e) / sqrt(d)): the scores leave the MFMAs in the exponent's units (see softmax_step)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t w = qf[ks][qb][e];
+                    qf[ks][qb][e] = LP<T>::pack2(LP<T>::to_float((uint16_t)(w & 0xffffu)) * c, LP<T>::to_float((uint16_t)(w >> 16)) * c);
+                }
+#endif
     }
 
     f32x4 oacc[DB][2];                                    // O^T: d rows 16*db + 4*g + r, query column qb
@@ -147,6 +167,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if FA_PP16_FOLD_MAX
+    f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // -m_run, the C operand every score block starts from
+#endif
     float m_run[2] = {kNegBig, kNegBig}, l_run[2] = {0.f, 0.f};      // per query column; l_run is this lane's PARTIAL row sum (its 4 of every 16 keys)
 
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
@@ -195,8 +218,13 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         } else {
             constexpr int i = j - NPV, ks = i / NKB, kb = i % NKB;
             if constexpr (ks == 0) {                               // (previous MFMA on this accumulator: NKB fragments back)
+#if FA_PP16_FOLD_MAX
+                LP<T>::mfma16_init(sacc[kb][0], fr, qf[ks][0], negm[0]);
+                LP<T>::mfma16_init(sacc[kb][1], fr, qf[ks][1], negm[1]);
+#else
                 LP<T>::mfma16_zero(sacc[kb][0], fr, qf[ks][0]);
                 LP<T>::mfma16_zero(sacc[kb][1], fr, qf[ks][1]);
+#endif
             } else {
                 LP<T>::mfma16_acc(sacc[kb][0], fr, qf[ks][0]);
                 LP<T>::mfma16_acc(sacc[kb][1], fr, qf[ks][1]);
@@ -269,6 +297,70 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         // running max is still -1e30) the wave reduces the row maxima; if some row outgrew its running max by more than 2^kPpDeferLog2 the max is
         // refreshed, l and O are rescaled and the SAME pass runs once more (now every term is <= 1); if not, the pass already holds exactly
         // what the exact path would compute.
+#if FA_PP16_FOLD_MAX
+        // The scores arrive as x = s * log2(e)/sqrt(d) - m_run (Q is pre-scaled, the MFMA chain starts from -m_run): P = exp2(x), no
+        // multiply-subtract per score.  `dm` is what the running max has moved by since the MFMAs of THIS tile were issued: 0 on the hot path.
+        float dm[2] = {0.f, 0.f};
+        if constexpr (decltype(maybe_first)::value) {
+            // tile 0 meets an empty running max (its scores started from 0): seed it with the tile's row maxima; no O or l to rescale yet
+            if (u == 0) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float mx = sacc[0][qb][0];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kb][qb][r]);
+                    m_run[qb] = fmaxf(kNegBig, max4(mx));      // (a row with no visible key keeps the floor: it never sees one later either)
+                    dm[qb] = m_run[qb];
+                    negm[qb] = f32x4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
+                }
+            }
+        }
+        float ps[2];
+        for (int attempt = 0;; ++attempt) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                ps[qb] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const float p0 = fast_exp2(sacc[kb][qb][0] - dm[qb]), p1 = fast_exp2(sacc[kb][qb][1] - dm[qb]);
+                    const float p2 = fast_exp2(sacc[kb][qb][2] - dm[qb]), p3 = fast_exp2(sacc[kb][qb][3] - dm[qb]);
+                    ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3;
+                    if (kb & 1) { pf[kb >> 1][qb].z = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].w = LP<T>::pack2(p2, p3); }
+                    else { pf[kb >> 1][qb].x = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].y = LP<T>::pack2(p2, p3); }
+                }
+            }
+            if (attempt != 0 || __builtin_amdgcn_ballot_w64(!(ps[0] <= 64.0f && ps[1] <= 64.0f)) == 0) break;
+            float mx[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                mx[qb] = sacc[0][qb][0];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx[qb] = fmaxf(mx[qb], sacc[kb][qb][r]);
+                mx[qb] = max4(mx[qb]) - dm[qb];                 // how far the tile's row max stands above the running max
+            }
+            // (one decision for both query columns: refreshing a column that did not need it is exact too)
+            if (__builtin_amdgcn_ballot_w64(mx[0] > kPpDeferLog2 || mx[1] > kPpDeferLog2) == 0) break;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float up = fmaxf(mx[qb], 0.f);
+                const float alpha = fast_exp2(-up);
+                m_run[qb] += up;
+                dm[qb] += up;
+                negm[qb] = f32x4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[db][qb][r] *= alpha;
+            }
+        }
+        l_run[0] += ps[0];
+        l_run[1] += ps[1];
+#else
         // Tile 0 meets an empty running max: its first pass would always be thrown away, so the running max is seeded with the tile's row
         // maxima (no O or l to rescale yet) and the pass below stands at once.
         if constexpr (decltype(maybe_first)::value) {
@@ -330,6 +422,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         }
         l_run[0] += ps[0];
         l_run[1] += ps[1];
+#endif
     };
     auto advance_ring = [&]() __attribute__((always_inline)) {
         ring_um1 = ring_u;
@@ -351,7 +444,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             const float l_tot = sum4(l_run[qb]);
             // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
             const float inv = l_tot != 0.f ? fast_rcp(l_tot) : 0.f;
-            const float lse = l_tot != 0.f ? (m_run[qb] * c + fast_log2(l_tot)) * kLn2 : 0.f;
+            const float lse = l_tot != 0.f ? (m_run[qb] * (FA_PP16_FOLD_MAX ? 1.0f : c) + fast_log2(l_tot)) * kLn2 : 0.f;
             const int row = q_row_a + 16 * qb;
             if (g == 0 && row < rows_here) lse_bh[t * kFwdBlockM + row] = lse;
 #pragma unroll

@@ -96,8 +96,8 @@ def lib():
         L.fa_device_clock_khz.restype = ctypes.c_int
         L.fa_fwd_kernel_name.argtypes = [_i32]
         L.fa_fwd_kernel_name.restype = ctypes.c_char_p
-        L.fa_set_fwd_kernel_policy.argtypes = [_i32]
-        L.fa_set_fwd_kernel_policy.restype = _i32
+        L.fa_set_kernel_policy.argtypes = [_i32]
+        L.fa_set_kernel_policy.restype = _i32
         _lib = L
     return _lib
 
@@ -110,14 +110,14 @@ def fwd_kernel_name(d) -> str:
     return lib().fa_fwd_kernel_name(int(d)).decode()
 
 
-FWD_POLICY_MFMA32, FWD_POLICY_MFMA16, FWD_POLICY_BY_SIZE = 0, 1, 2
+POLICY_MFMA32, POLICY_MFMA16, POLICY_AUTO = 0, 1, 2
 
 
-def set_fwd_kernel_policy(policy) -> int:
-    """fa_set_fwd_kernel_policy: which head_dim-128 forward kernel serves a launch; returns the previous policy"""
-    prev = lib().fa_set_fwd_kernel_policy(int(policy))
+def set_kernel_policy(policy) -> int:
+    """fa_set_kernel_policy: which head_dim-128 kernel set (32x32x16 / 16x16x32 MFMA tiles) serves a launch; returns the previous policy"""
+    prev = lib().fa_set_kernel_policy(int(policy))
     if prev < 0:
-        raise ValueError(f"unknown forward kernel policy {policy}")
+        raise ValueError(f"unknown kernel policy {policy}")
     return prev
 
 

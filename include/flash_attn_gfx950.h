@@ -205,14 +205,15 @@ double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, in
  * has two kernels: launches of fewer than 2^29 (query, key) pairs (2^31 visible pairs under a causal mask) run fa_fwd_pp_kernel,
  * larger ones fa_fwd_pp16_kernel. */
 const char* fa_fwd_kernel_name(int32_t d);
-/* Which of the two head_dim-128 forward kernels serves a launch: FA_FWD_POLICY_BY_SIZE (the default) as described above,
- * FA_FWD_POLICY_MFMA32 / FA_FWD_POLICY_MFMA16 pin one of them for every launch.  Both kernels meet the same tolerances; they differ in
- * speed only (the 16x16x32 one draws less power per FLOP and wins where the chip's power cap binds).  Process-wide, thread-safe;
- * returns the previous policy, -1 (and changes nothing) for an unknown value.  The reference has no counterpart. */
-#define FA_FWD_POLICY_MFMA32 0
-#define FA_FWD_POLICY_MFMA16 1
-#define FA_FWD_POLICY_BY_SIZE 2
-int32_t fa_set_fwd_kernel_policy(int32_t policy);
+/* head_dim 128 has two sets of kernels, tiled for v_mfma_f32_32x32x16 and for v_mfma_f32_16x16x32.  Both meet the same tolerances;
+ * they differ in speed only: the 16x16x32 shape draws less power per FLOP and wins where the chip's power cap binds (long launches),
+ * the 32x32x16 forward needs fewer cycles and wins short ones.  FA_POLICY_AUTO (the default): forward and dK/dV by launch size (forward as described
+ * above, dK/dV from 2^31 pairs), dQ 16x16x32 unless the mask is causal; FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
+ * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 is not affected.  The reference has no counterpart. */
+#define FA_POLICY_MFMA32 0
+#define FA_POLICY_MFMA16 1
+#define FA_POLICY_AUTO 2
+int32_t fa_set_kernel_policy(int32_t policy);
 /* Peak shader clock of `device` in kHz (hipDeviceAttributeClockRate), or a negative HIP error code: with 256 CUs x 4096 FLOP/clk/CU
  * it derives the dense fp16 MFMA peak a benchmark quotes (256 x 2.4 GHz x 4096 = 2.5 PFLOP/s). */
 int fa_device_clock_khz(int32_t device);

@@ -18,11 +18,11 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_forward_kernel_policy_is_host_state():
-    """fa_set_fwd_kernel_policy: returns the previous value, refuses unknown ones, and fa_fwd_kernel_name follows it (no GPU involved)"""
-    assert capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA32) == capi.FWD_POLICY_BY_SIZE      # the library's initial policy
+    """fa_set_kernel_policy: returns the previous value, refuses unknown ones, and fa_fwd_kernel_name follows it (no GPU involved)"""
+    assert capi.set_kernel_policy(capi.POLICY_MFMA32) == capi.POLICY_AUTO      # the library's initial policy
     assert capi.fwd_kernel_name(128) == "fa_fwd_pp_kernel"
-    assert capi.lib().fa_set_fwd_kernel_policy(3) == -1 and capi.lib().fa_set_fwd_kernel_policy(-1) == -1
-    assert capi.set_fwd_kernel_policy(capi.FWD_POLICY_BY_SIZE) == capi.FWD_POLICY_MFMA32
+    assert capi.lib().fa_set_kernel_policy(3) == -1 and capi.lib().fa_set_kernel_policy(-1) == -1
+    assert capi.set_kernel_policy(capi.POLICY_AUTO) == capi.POLICY_MFMA32
     assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel" and capi.fwd_kernel_name(64) == "fa_fwd_pp_kernel"
 
 

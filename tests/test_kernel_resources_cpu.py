@@ -8,9 +8,9 @@ import pytest
 
 from _kernel_isa import analyse
 
-FILES = ["fa_fwd_pp.hip", "fa_fwd_pp16.hip", "fa_bwd.hip"]
+FILES = ["fa_fwd_pp.hip", "fa_fwd_pp16.hip", "fa_bwd.hip", "fa_bwd_dq16.hip", "fa_bwd_dkdv16.hip"]
 # whole-kernel scratch that is known, outside every loop (prologue / epilogue), and bounded here so growth is noticed
-SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 112, "fa_bwd_dq_kernel": 64}      # dK/dV: D = 64 causal carries 100 B since the second (workspace) epilogue
+SCRATCH_ALLOWED = {"fa_bwd_dkdv_kernel": 112, "fa_bwd_dq_kernel": 64, "fa_bwd_dkdv16_kernel": 32}      # dK/dV: D = 64 causal carries 100 B since the second (workspace) epilogue
 # scratch ops INSIDE an MFMA loop: zero everywhere since round 3 (rounds 1-2 allowed the two D = 64 backward kernels, squeezed to 128
 # registers for two workgroups per CU, 1-4 spill ops per tile).  (kernel substring, head-dim substring) -> max ops per loop.
 # Accumulator shuffles: never.
@@ -54,7 +54,7 @@ def test_whole_kernel_scratch_is_zero_or_on_the_allow_list(kernels):
 
 def test_two_waves_per_simd_for_the_eight_wave_kernels(kernels):
     for (f, name), info in kernels.items():
-        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_fwd_pp16_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel")):
+        if any(k in name for k in ("fa_fwd_pp_kernel", "fa_fwd_pp16_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dq_kernel", "fa_bwd_dq16_kernel", "fa_bwd_dkdv16_kernel")):
             assert info["occupancy"] >= 2, (f, name, info["occupancy"])
 
 

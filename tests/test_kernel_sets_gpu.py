@@ -1,6 +1,10 @@
-"""GPU: the second head_dim-128 forward kernel (fa_fwd_pp16.hip, v_mfma_f32_16x16x32 tiles).
+"""GPU: both head_dim-128 kernel sets (v_mfma_f32_32x32x16 and v_mfma_f32_16x16x32 tiles) over the whole test grid.
 
-The launcher gives it the LARGE launches only (>= 2^29 (query, key) pairs, 2^31 under a causal mask: include/flash_attn_gfx950.h, fa_set_fwd_kernel_policy), so
+Under the default policy the forward and dK/dV pick by launch size and dQ by the mask (include/flash_attn_gfx950.h,
+fa_set_kernel_policy), so the rest of the suite reaches fa_fwd_pp16.hip / fa_bwd_dkdv16.hip only in the full-size tests and the 32x32x16
+dQ at head_dim 128 only under a causal mask.  Every test below runs twice: pinned to the 16x16x32 set and pinned to the 32x32x16 set.
+
+The launcher gives it the LARGE launches only (>= 2^29 (query, key) pairs, 2^31 under a causal mask: include/flash_attn_gfx950.h, fa_set_kernel_policy), so
 of the suite only the full-size value-parity and property tests reach it on their own.  This module pins the policy to that kernel
 and runs the forward-facing tests of the other modules again at head_dim 128: the golden vectors, the C-oracle cases, the
 reference's (sq, sk) grid, packed sequences, the softmax edge cases - every tail, mask and head-group path of the kernel.  It also
@@ -17,14 +21,14 @@ import test_properties_gpu as TP
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def pin_mfma16(gpu):
+@pytest.fixture(autouse=True, params=["mfma16", "mfma32"])
+def pinned_set(gpu, request):
     from flash_attn_turing import capi
 
-    prev = capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA16)
-    assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel"
-    yield
-    capi.set_fwd_kernel_policy(prev)
+    prev = capi.set_kernel_policy(capi.POLICY_MFMA16 if request.param == "mfma16" else capi.POLICY_MFMA32)
+    assert capi.fwd_kernel_name(128) == ("fa_fwd_pp16_kernel" if request.param == "mfma16" else "fa_fwd_pp_kernel")
+    yield request.param
+    capi.set_kernel_policy(prev)
 
 
 def _d128_golden():
@@ -93,37 +97,45 @@ def test_launch_path_is_hip_graph_capturable(gpu):
     TP.test_launch_path_is_hip_graph_capturable(gpu)
 
 
-def test_policy_switches_kernels_and_both_agree(gpu):
-    """the same problem through both kernels: equal within two roundings of the output format (they sum the same products in a
-    different order), LSE to 1e-5; an unknown policy is refused and changes nothing"""
+def test_policy_switches_kernels_and_both_agree(gpu, pinned_set):
+    """the same problem through both kernel sets: equal within two roundings of the output format (they sum the same products in a
+    different order), LSE to 1e-5; the default policy gives a small causal launch the 32x32x16 set; an unknown
+    policy is refused and changes nothing"""
     import flash_attn_turing as F
     from flash_attn_turing import capi
 
+    if pinned_set != "mfma16":
+        pytest.skip("one pass is enough")
     gen = torch.Generator(device=gpu).manual_seed(5)
-    q, k, v = (torch.randn(2, 777, 4, 128, device=gpu, dtype=torch.float16, generator=gen) for _ in range(3))
+    q, k, v, do = (torch.randn(2, 777, 4, 128, device=gpu, dtype=torch.float16, generator=gen) for _ in range(4))
     outs = {}
-    for pol in (capi.FWD_POLICY_MFMA32, capi.FWD_POLICY_MFMA16, capi.FWD_POLICY_BY_SIZE):
-        capi.set_fwd_kernel_policy(pol)
+    for pol in (capi.POLICY_MFMA32, capi.POLICY_MFMA16, capi.POLICY_AUTO):
+        capi.set_kernel_policy(pol)
         o, lse = F.fwd(q, k, v, True)
+        grads = F.bwd(q, k, v, o, lse, do, True)
         torch.cuda.synchronize()
-        outs[pol] = (o.float(), lse)
-    assert torch.equal(outs[capi.FWD_POLICY_BY_SIZE][0], outs[capi.FWD_POLICY_MFMA32][0])          # a small launch: the 32x32x16 kernel
-    assert not torch.equal(outs[capi.FWD_POLICY_MFMA16][0], outs[capi.FWD_POLICY_MFMA32][0])       # (different summation order)
-    assert (outs[capi.FWD_POLICY_MFMA16][0] - outs[capi.FWD_POLICY_MFMA32][0]).abs().max().item() <= 2e-3
-    assert (outs[capi.FWD_POLICY_MFMA16][1] - outs[capi.FWD_POLICY_MFMA32][1]).abs().max().item() <= 1e-5
+        outs[pol] = (o.float(), lse) + tuple(t.float() for t in grads)
+    m32, m16, auto = outs[capi.POLICY_MFMA32], outs[capi.POLICY_MFMA16], outs[capi.POLICY_AUTO]
+    assert torch.equal(auto[0], m32[0])                              # a small causal launch: the 32x32x16 set throughout
+    assert all(torch.equal(a, b) for a, b in zip(auto[2:], m32[2:]))
+    assert not torch.equal(m16[0], m32[0])                           # (different summation order)
+    assert not any(torch.equal(a, b) for a, b in zip(m16[2:], m32[2:]))
+    assert (m16[0] - m32[0]).abs().max().item() <= 2e-3 and (m16[1] - m32[1]).abs().max().item() <= 1e-5
+    for a, b in zip(m16[2:], m32[2:]):
+        assert (a - b).abs().max().item() <= 8e-3                    # gradients of N(0,1) data reach ~4: two fp16 roundings there
     with pytest.raises(ValueError):
-        capi.set_fwd_kernel_policy(7)
-    assert capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA16) == capi.FWD_POLICY_BY_SIZE
+        capi.set_kernel_policy(7)
+    assert capi.set_kernel_policy(capi.POLICY_MFMA16) == capi.POLICY_AUTO
 
 
 @pytest.mark.parametrize("name", ["c2_fwd_4k", "c3_fwd_16k_causal"])
 def test_mfma32_kernel_values_at_baseline_sizes(gpu, name):
     """the policy gives these sizes to the 16x16x32 kernel (tests/test_value_parity_gpu.py checks it there); the 32x32x16 kernel must
-    stay value-correct at them too - it serves them under FA_FWD_POLICY_MFMA32"""
+    stay value-correct at them too - it serves them under FA_POLICY_MFMA32"""
     import test_value_parity_gpu as TV
     from flash_attn_turing import capi
 
-    capi.set_fwd_kernel_policy(capi.FWD_POLICY_MFMA32)
+    capi.set_kernel_policy(capi.POLICY_MFMA32)
     TV._cache.clear()
     try:
         TV.test_forward_values_row_blocks_vs_c_oracle(gpu, name)

@@ -46,10 +46,10 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, const float
     for (int i = 0; i < 4; ++i) s += d0[i] + d1[i] + d2[i] + d3[i] + d4[i] + d5[i] + d6[i] + d7[i];
     if (s == 1234.5f) out[1] = 1;
 }
-#define VALU4(a, b, c, d) asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define VALU4(a, b, c, d) if constexpr (WITH_VALU) asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // the forward kernel's mix per 32768 FLOP: 4 VALU + 1 KiB of LDS reads, around one 32x32x16 or two 16x16x32 MFMAs (fp16, N(0,1) operands)
-template <int SMALL>
+template <int SMALL, int NLDS = 4, int WITH_VALU = 1>
 __global__ __launch_bounds__(512, 2) void kmix(unsigned long long* out, const float* src, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned int lds[16384];
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = i * 2654435761u;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void kmix(unsigned long long* out, const fl
                 d6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, d6, 0, 0, 0); d7 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, d7, 0, 0, 0); VALU4(r[4], r[5], r[6], r[7]);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NLDS; ++q) {
                 asm volatile("" :: "v"(ld[q & 3]));
                 const unsigned int a0 = lbase + (((it * 4 + j + q * 7) & 7) * 8192u);
                 asm volatile("ds_read_b128 %0, %1" : "=v"(ld[q & 3]) : "v"(a0));
@@ -131,6 +131,17 @@ int main() {
         double* t = tm[v];
         for (int a = 0; a < 5; ++a) for (int b = a + 1; b < 5; ++b) if (t[b] < t[a]) { double x = t[a]; t[a] = t[b]; t[b] = x; }
         printf("%-16s %-14s %8.0f %8.0f %8.0f   + 4 VALU + 1 KiB LDS reads per 32768 FLOP (the forward kernel's mix)\n", v ? "16x16x32 f16" : "32x32x16 f16", dn[0], t[0], t[2], t[4]);
+    }
+    // where the mix's power goes (16x16x32 f16, N(0,1) operands): LDS reads per 32768 FLOP x VALU on / off.  0.5 KiB = a wave keeping 64
+    // query rows (each fragment feeds four MFMAs), 0.75 KiB = 48 rows
+    struct M { const char* label; kfn f; } ms[] = {{"no LDS, no VALU", kmix<1, 0, 0>}, {"no LDS, 4 VALU", kmix<1, 0, 1>}, {"1 KiB LDS, no VALU", kmix<1, 4, 0>},
+                                                  {"0.5 KiB LDS, 4 VALU", kmix<1, 2, 1>}, {"0.75 KiB LDS, 4 VALU", kmix<1, 3, 1>}, {"1 KiB LDS, 4 VALU", kmix<1, 4, 1>}};
+    double tx[6][5];
+    for (int r = 0; r < 5; ++r) for (int v = 0; v < 6; ++v) tx[v][r] = time_one(ms[v].f, d, src[0]);
+    for (int v = 0; v < 6; ++v) {
+        double* t = tx[v];
+        for (int a = 0; a < 5; ++a) for (int b = a + 1; b < 5; ++b) if (t[b] < t[a]) { double x = t[a]; t[a] = t[b]; t[b] = x; }
+        printf("%-16s %-14s %8.0f %8.0f %8.0f   mix: %s per 32768 FLOP\n", "16x16x32 f16", dn[0], t[0], t[2], t[4], ms[v].label);
     }
     return 0;
 }
