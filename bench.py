@@ -494,7 +494,8 @@ def bwd_rooflines(torch, capi, et, causal, b, s, h, d):
     ws = capi.attach_workspace(p, et["q"])      # noqa: F841  (dK/dV scratch for GQA / MQA shapes; None at the MHA bench shapes)
     pair = b * h * float(s) * s * (0.5 if causal else 1.0)
     out = {}
-    for name, kern, flop_mult in (("dot_do_o", "fa_bwd_dot_do_o_kernel", 0), ("dq", "fa_bwd_dq_kernel", 6), ("dkdv", "fa_bwd_dkdv_kernel", 8)):
+    for name, kern, flop_mult in (("dot_do_o", "fa_bwd_dot_do_o_kernel", 0), ("dq", capi.kernel_name("dq", b, s, s, h, d, causal), 6),
+                                  ("dkdv", capi.kernel_name("dkdv", b, s, s, h, d, causal), 8)):
         f = lambda: capi.bwd_stage(name, p)
         f(); torch.cuda.synchronize()
         ms = event_time_ms(torch, f, 5, reps=5)
@@ -577,7 +578,7 @@ def main():
     value = flops_rank * dist.world / (wall / args.steps) / 1e12
 
     # dominant-kernel roofline: forward kernel alone, HIP events on the launch stream
-    fwd_kernel = capi.fwd_kernel_name(d)
+    fwd_kernel = capi.kernel_name("fwd", b, s, s, h, d, causal)      # the kernel THIS workload's launches go to
     fwd_only = lambda: capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
     k_ms = event_time_ms(torch, fwd_only, max(5, args.steps))
     k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12

@@ -789,6 +789,9 @@ static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
     // (the bound b * max_seqlen, never total_q / total_k: the optional hints must not change which kernel, hence which bits, a call gets)
     return (int64_t)kp.b * kp.seqlen_q * kp.seqlen_k * kp.h / (kp.is_causal ? 2 : 1) >= kKvMfma16MinPairs;
 }
+const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv) {
+    return dkdv ? (bwd_use_mfma16(kp, true) ? "fa_bwd_dkdv16_kernel" : "fa_bwd_dkdv_kernel") : (bwd_use_mfma16(kp, false) ? "fa_bwd_dq16_kernel" : "fa_bwd_dq_kernel");
+}
 hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s);      // fa_bwd_dq16.hip (head_dim 128, v_mfma_f32_16x16x32)
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);

@@ -559,6 +559,8 @@ static bool use_mfma16(const FwdKernelParams& kp) {
 // the kernel that serves the LARGE problems of a head dimension (what a profile of the BASELINE configurations shows)
 const char* fwd_kernel_name(int d) { return d == 128 && g_fwd_policy.load(std::memory_order_relaxed) != 0 ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
 
+const char* fwd_kernel_name_for(const FwdKernelParams& kp) { return use_mfma16(kp) ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
+
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;

@@ -96,6 +96,8 @@ def lib():
         L.fa_device_clock_khz.restype = ctypes.c_int
         L.fa_fwd_kernel_name.argtypes = [_i32]
         L.fa_fwd_kernel_name.restype = ctypes.c_char_p
+        L.fa_kernel_name.argtypes = [_i32] * 7
+        L.fa_kernel_name.restype = ctypes.c_char_p
         L.fa_set_kernel_policy.argtypes = [_i32]
         L.fa_set_kernel_policy.restype = _i32
         _lib = L
@@ -108,6 +110,14 @@ def device_clock_khz(device_index=0) -> int:
 
 def fwd_kernel_name(d) -> str:
     return lib().fa_fwd_kernel_name(int(d)).decode()
+
+
+STAGES = {"fwd": 0, "dq": 1, "dkdv": 2}
+
+
+def kernel_name(stage, b, seqlen_q, seqlen_k, h, d, causal) -> str:
+    """fa_kernel_name: the kernel a launch of this shape goes to under the current policy (stage: "fwd", "dq", "dkdv")"""
+    return lib().fa_kernel_name(STAGES[stage], int(b), int(seqlen_q), int(seqlen_k), int(h), int(d), int(bool(causal))).decode()
 
 
 POLICY_MFMA32, POLICY_MFMA16, POLICY_AUTO = 0, 1, 2

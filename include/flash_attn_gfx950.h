@@ -214,6 +214,12 @@ const char* fa_fwd_kernel_name(int32_t d);
 #define FA_POLICY_MFMA16 1
 #define FA_POLICY_AUTO 2
 int32_t fa_set_kernel_policy(int32_t policy);
+/* Name of the kernel a launch of this shape is dispatched to under the current policy (what a profiler's kernel trace will show):
+ * stage FA_STAGE_FWD / FA_STAGE_DQ / FA_STAGE_DKDV; seqlen_* = the max_seqlen_* of a packed call.  "" for an unknown stage. */
+#define FA_STAGE_FWD 0
+#define FA_STAGE_DQ 1
+#define FA_STAGE_DKDV 2
+const char* fa_kernel_name(int32_t stage, int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal);
 /* Peak shader clock of `device` in kHz (hipDeviceAttributeClockRate), or a negative HIP error code: with 256 CUs x 4096 FLOP/clk/CU
  * it derives the dense fp16 MFMA peak a benchmark quotes (256 x 2.4 GHz x 4096 = 2.5 PFLOP/s). */
 int fa_device_clock_khz(int32_t device);

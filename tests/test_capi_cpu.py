@@ -24,6 +24,17 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.lib().fa_set_kernel_policy(3) == -1 and capi.lib().fa_set_kernel_policy(-1) == -1
     assert capi.set_kernel_policy(capi.POLICY_AUTO) == capi.POLICY_MFMA32
     assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel" and capi.fwd_kernel_name(64) == "fa_fwd_pp_kernel"
+    # fa_kernel_name: the default policy's choices at the BASELINE shapes and at small ones
+    assert capi.kernel_name("fwd", 4, 16384, 16384, 32, 128, True) == "fa_fwd_pp16_kernel"
+    assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 128, False) == "fa_fwd_pp16_kernel"
+    assert capi.kernel_name("fwd", 1, 512, 512, 4, 128, False) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dq16_kernel"
+    assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, True) == "fa_bwd_dq_kernel"
+    assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dkdv16_kernel"
+    assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 128, False) == "fa_bwd_dkdv_kernel"
+    assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, False) == "fa_bwd_dkdv_kernel"
+    assert capi.lib().fa_kernel_name(9, 1, 1, 1, 1, 128, 0) == b""
 
 
 def test_flops_and_bytes_match_survey_figures():
