@@ -29,7 +29,7 @@ def points():
                 yield d, causal, s
 
 
-KERNELS = (("fa_fwd_pp", "fwd", 4.0), ("fa_bwd_dq_kernel", "dq", 6.0), ("fa_bwd_dkdv_kernel", "dkdv", 8.0))   # name prefix (fa_fwd_pp_kernel / fa_fwd_pp16_kernel by problem size), tag, EXECUTED flop multiple of b*h*sq*sk*d
+KERNELS = (("fa_fwd_pp", "fwd", 4.0), ("fa_bwd_dq", "dq", 6.0), ("fa_bwd_dkdv", "dkdv", 8.0))   # name prefix (fa_fwd_pp_kernel / fa_fwd_pp16_kernel by problem size), tag, EXECUTED flop multiple of b*h*sq*sk*d
 
 
 def run_workload():
