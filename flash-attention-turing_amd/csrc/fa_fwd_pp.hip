@@ -529,7 +529,8 @@ static hipError_t launch_pp_t(const FwdKernelParams& kp, uint32_t grid, hipStrea
 // and wave instead of 32, the same LDS traffic).  The chip runs these kernels against its power cap; the 16x16x32 shape draws less per
 // FLOP (tools/powerbench: 1.98 vs 1.66 PFLOP/s on N(0,1) data) and the kernel runs at ~1.87 GHz instead of ~1.55, but it needs ~12 % more
 // cycles (twice the MFMA issue slots on the VALU port).  It wins 3-5 % where the cap binds - long launches - and loses 2-10 % on short ones
-// (profiles/r3_fwd_mfma16_ab.log), so the launcher picks by the number of (query, key) pairs a launch computes.
+// (profiles/r3_fwd_mfma16_ab.log), so the launcher picks by the (query, key) pairs PER HEAD, seqlen_q * seqlen_k - not by batch or head count:
+// a (batch, head) shard of a problem must get the kernel, hence the bits, the whole problem gets (flash_attn_turing/sharding.py).
 // FA_FWD_MFMA16: the policy a process starts with, 0 = never, 1 = always, 2 = by size (default); fa_set_kernel_policy() changes it
 // (tests run the whole forward grid through either kernel; a deployment that knows its launches are short can pin the 32x32x16 one).
 #ifndef FA_FWD_MFMA16
@@ -541,19 +542,18 @@ int set_kernel_policy(int policy) {
     if (policy < 0 || policy > 2) return -1;
     return g_fwd_policy.exchange(policy, std::memory_order_relaxed);
 }
-constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 29;             // b4 h32 s2048 non-causal
-constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 31;       // b4 h16 s8192 causal (visible pairs); under a causal mask the late waves of a workgroup
-                                                                     // idle while the early ones finish, the cap binds less, and the break-even moves up
+constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 22;             // 2048 x 2048
+constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 26;       // 8192 x 8192: under a causal mask the late waves of a workgroup idle while the early
+                                                                     // ones finish, the cap binds less, and the break-even moves up
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
 
 static bool use_mfma16(const FwdKernelParams& kp) {
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
     if (kp.d != 128 || policy == 0) return false;
     if (policy == 1) return true;
-    // (packed sequences: the bound b * max_seqlen_q, NOT total_q - the optional hint must not change which kernel, hence which bits,
+    // (packed sequences: max_seqlen_q x max_seqlen_k; never total_q - the optional hint must not change which kernel, hence which bits,
     // a call gets: tests/test_fuzz_gpu.py compares the compact and the plain varlen grid bit for bit)
-    const int64_t pairs = (int64_t)kp.b * kp.seqlen_q * kp.seqlen_k * kp.h / (kp.is_causal ? 2 : 1);
-    return pairs >= (kp.is_causal ? kFwdMfma16MinPairsCausal : kFwdMfma16MinPairs);
+    return (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kFwdMfma16MinPairsCausal : kFwdMfma16MinPairs);
 }
 
 // the kernel that serves the LARGE problems of a head dimension (what a profile of the BASELINE configurations shows)

@@ -1,6 +1,6 @@
 """GPU: both head_dim-128 kernel sets (v_mfma_f32_32x32x16 and v_mfma_f32_16x16x32 tiles) over the whole test grid.
 
-Under the default policy the forward and dK/dV pick by launch size and dQ by the mask (include/flash_attn_gfx950.h,
+Under the default policy the forward and dK/dV pick by seqlen_q * seqlen_k and dQ by the mask (include/flash_attn_gfx950.h,
 fa_set_kernel_policy), so the rest of the suite reaches fa_fwd_pp16.hip / fa_bwd_dkdv16.hip only in the full-size tests and the 32x32x16
 dQ at head_dim 128 only under a causal mask.  Every test below runs twice: pinned to the 16x16x32 set and pinned to the 32x32x16 set.
 
