@@ -33,6 +33,9 @@ constexpr float kPpDeferLog2 = 6.0f;
 #ifndef FA_PP16_FOLD_MAX
 #define FA_PP16_FOLD_MAX 0
 #endif
+#ifndef FA_PP16_PF
+#define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
+#endif
 
 template <typename T, int D, bool CAUSAL, int BN>
 __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp16_kernel(const FwdKernelParams p) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     // One matrix phase = NPV P.V fragments (V(u-1)) + NQK QK^T fragments (K(u)); every fragment feeds TWO MFMAs (the lane's two query columns),
     // so LDS bytes per FLOP are those of the 32x32x16 kernel.  Fragment j + PF is requested before the MFMAs of fragment j.
-    constexpr int NPV = NC * DB, NQK = NKB * KS, NST = NPV + NQK, PF = 4;
+    constexpr int NPV = NC * DB, NQK = NKB * KS, NST = NPV + NQK, PF = FA_PP16_PF;
     auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
         if (j < NPV) {
             const int db = j % DB, cch = j / DB;
