@@ -8,12 +8,15 @@
 //   fa_bwd_dkdv_kernel      dV = sum_i P_ij^T dO_i, dK = scale * sum_i dS_ij^T Q_i   (:842-1676)
 //   fa_bwd_sum_splits_kernel  adds the fp32 partial dK / dV planes when the dK/dV launch split a GQA head group (C ABI 3)
 //
+// (head_dim 128 has a second dQ and a second dK/dV kernel, tiled for v_mfma_f32_16x16x32: fa_bwd_dq16.hip, fa_bwd_dkdv16.hip; the launchers at
+// the end of this file pick per launch.)
+//
 // A backward call is TWO launches on one stream, dQ then dK/dV (plus the plane sum when split): the dQ kernel computes D for
 // its own rows in its prologue and leaves it in dsoftmax_sum for dK/dV; the stand-alone dot_do_o kernel stays as an entry point.
 // ("workspace" below always means the optional fp32 dK / dV scratch of C ABI 3, never D.)
 //
-// Like the reference this is the deterministic, atomics-free 7-GEMM form (S and dP are
-// recomputed in both kernels).  Differences that matter on CDNA4:
+// Like the reference's alternative this is the deterministic, atomics-free 7-GEMM form (S and dP are recomputed in both kernels); fp32
+// atomics run at 1.33 TB/s on this chip, the single-kernel form would spend 26 ms accumulating dQ at C4 (profiles/r3_atomicbench.log).  Differences that matter on CDNA4:
 //   * dQ kernel uses the forward's "swapped" layout (lane = query column), so LSE_i and D_i
 //     are lane scalars and dS^T feeds the dQ^T MFMA straight from registers;
 //   * dK/dV kernel uses the un-swapped layout (lane = key column), P and dS feed the dV^T / dK^T

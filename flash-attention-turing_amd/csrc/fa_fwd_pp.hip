@@ -23,6 +23,9 @@
 //     hand-pipelined stream of MFMAs with LDS fragments requested 4 steps ahead; at D = 128 the loop runs three tiles per trip
 //     so that ring slots are compile-time constants (no address arithmetic left in it).
 //
+// head_dim 128 has a second kernel with the same schedule tiled for v_mfma_f32_16x16x32 (fa_fwd_pp16.hip); launch_fwd at the end of this file
+// picks per launch (fa_set_kernel_policy).
+//
 // Semantics follow SURVEY.md Appendix A; dead rows produce O = 0 and LSE = 0.0
 // (flash_fwd_kernel.h:720-728,767-771) without relying on a zero pre-fill of the outputs.
 // Earlier alternatives (one-barrier-per-tile baseline, 4-wave variant, single-stream software pipeline) and the
