@@ -128,16 +128,56 @@ def test_policy_switches_kernels_and_both_agree(gpu, pinned_set):
     assert capi.set_kernel_policy(capi.POLICY_MFMA16) == capi.POLICY_AUTO
 
 
-@pytest.mark.parametrize("name", ["c2_fwd_4k", "c3_fwd_16k_causal"])
-def test_mfma32_kernel_values_at_baseline_sizes(gpu, name):
-    """the policy gives these sizes to the 16x16x32 kernel (tests/test_value_parity_gpu.py checks it there); the 32x32x16 kernel must
-    stay value-correct at them too - it serves them under FA_POLICY_MFMA32"""
-    import test_value_parity_gpu as TV
-    from flash_attn_turing import capi
+def _other_set_than_default(pinned_set, default_is_mfma16):
+    """the BASELINE-size value checks of tests/test_value_parity_gpu.py run under the default policy; here they run for the kernel set
+    the default policy does NOT pick at that size"""
+    if (pinned_set == "mfma16") == default_is_mfma16:
+        pytest.skip("the default policy's kernel at this size is checked in tests/test_value_parity_gpu.py")
 
-    capi.set_kernel_policy(capi.POLICY_MFMA32)
+
+@pytest.mark.parametrize("name", ["c2_fwd_4k", "c3_fwd_16k_causal"])
+def test_forward_values_at_baseline_sizes_other_set(gpu, name, pinned_set):
+    import test_value_parity_gpu as TV
+
+    _other_set_than_default(pinned_set, True)          # default: fa_fwd_pp16_kernel at both sizes
     TV._cache.clear()
     try:
         TV.test_forward_values_row_blocks_vs_c_oracle(gpu, name)
     finally:
         TV._cache.clear()
+
+
+def test_backward_values_at_baseline_size_other_set(gpu, pinned_set):
+    """BASELINE configs[3] (bf16 8k forward + backward): key / row blocks of dK, dV, dQ against the C oracle"""
+    import test_value_parity_gpu as TV
+
+    _other_set_than_default(pinned_set, True)          # default: fa_bwd_dq16_kernel and fa_bwd_dkdv16_kernel (no mask, 8k)
+    TV._cache.clear()
+    try:
+        TV.test_backward_values_blocks_vs_c_oracle(gpu)
+    finally:
+        TV._cache.clear()
+
+
+def test_causal_backward_heads_at_baseline_shape_mfma16_dq(gpu, pinned_set):
+    """the causal fp16 C4 shape: the default policy runs the 32x32x16 dQ there (and the 16x16x32 dK/dV); whole heads against fp32 math with
+    the 16x16x32 dQ"""
+    import test_value_parity_gpu as TV
+
+    if pinned_set != "mfma16":
+        pytest.skip("the default policy's kernels at this size are checked in tests/test_value_parity_gpu.py")
+    TV._cache.clear()
+    try:
+        TV.test_backward_values_full_heads_vs_fp32(gpu, "c4_shape_causal_fp16")
+    finally:
+        TV._cache.clear()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("h,hk", [(8, 1), (32, 1)])
+def test_dkdv_head_group_split_matches_single_pass(gpu, h, hk, causal):
+    TP.test_dkdv_head_group_split_matches_single_pass(gpu, h, hk, 128, causal)
+
+
+def test_dkdv_split_on_packed_sequences_with_padding_rows(gpu):
+    TP.test_dkdv_split_on_packed_sequences_with_padding_rows(gpu)
