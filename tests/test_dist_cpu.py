@@ -136,9 +136,11 @@ def test_clockbench_parser_reads_the_current_table_and_reports_drift():
     sample = ("variant                                                   min   median      max  (TFLOP/s over 5 interleaved runs)\n"
               "MFMA only, 1 wave/SIMD                                   1413     1654     1655\n"
               "MFMA only, 2 waves/SIMD                                  1600     1656     1658\n"
+              "16x16x32 MFMA only, 2 waves/SIMD                         1911     1979     1984\n"
               "MFMA + 4 VALU, 2 waves/SIMD                              1357     1404     1405\n")
     got = bench.parse_clockbench(sample)
     assert got["tflops"] == 1656 and got["min"] == 1600 and "2 waves/SIMD" in got["what"]
+    assert got["mfma_16x16x32"]["tflops"] == 1979          # reported beside, never as the round-to-round comparable ceiling
     old_format = "MFMA only, 2 waves/SIMD, all CUs   5.1 ms  s_memtime 8e6 ticks -> 1.6 GHz ; 1650 TFLOP/s ; 32 ticks/MFMA/SIMD\n"
     assert "error" in bench.parse_clockbench(old_format)
     assert "error" in bench.parse_clockbench("")

@@ -61,6 +61,23 @@ __global__ __launch_bounds__(512, 2) void k_mfma(unsigned long long* out, const 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = t1 - t0;
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+// the same FLOPs per iteration from v_mfma_f32_16x16x32_f16 (32 per iteration, 8 accumulators): the shape the head_dim-128 16x16x32 kernels use
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 2) void k_mfma16(unsigned long long* out, const _Float16* rnd, int iters) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = rnd[(threadIdx.x * 8 + i) & 4095]; b[i] = rnd[(threadIdx.x * 8 + i + 77) & 4095]; }
+    f32x4 d[8];
+    for (int i = 0; i < 8; ++i) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += d[i][0] + d[i][1] + d[i][2] + d[i][3];
+    if (s == 1234.5f) out[1] = 1;
+}
 struct Variant { const char* label; void (*fn)(unsigned long long*, const _Float16*, int); int wps; double tf[8]; int n; };
 static double time_one(void (*k)(unsigned long long*, const _Float16*, int), unsigned long long* d, _Float16* rnd, int wps) {
     const int iters = 20000, threads = 256 * wps;
@@ -81,6 +98,7 @@ int main() {
     Variant vs[] = {
         {"MFMA only, 1 wave/SIMD", k_mfma<0, 0, 0>, 1},
         {"MFMA only, 2 waves/SIMD", k_mfma<0, 0, 0>, 2},
+        {"16x16x32 MFMA only, 2 waves/SIMD", k_mfma16, 2},
         {"MFMA + 4 VALU, 1 wave/SIMD", k_mfma<1, 0, 0>, 1},
         {"MFMA + 4 VALU, 2 waves/SIMD", k_mfma<1, 0, 0>, 2},
         {"MFMA + 0.5 KB LDS/MFMA (b128), 2 w/SIMD", k_mfma<0, 2, 0>, 2},
