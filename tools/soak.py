@@ -20,13 +20,19 @@ SHAPES = [  # b, sq, sk, h, hk, d, dtype, causal
     (3, 1300, 700, 6, 3, 64, torch.bfloat16, True),         # sq > sk: dead rows
     (4, 2048, 2048, 32, 32, 64, torch.float16, False),
     (64, 512, 512, 8, 8, 128, torch.float16, True),         # many short workgroups
+    (1, 16384, 16384, 8, 8, 128, torch.float16, True),      # the headline's per-head problem (the 16x16x32 forward under every policy but mfma32)
+    (2, 300, 4100, 4, 2, 128, torch.bfloat16, False),       # few rows, long ragged key axis
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--policy", default="auto", choices=["auto", "mfma16", "mfma32"], help="head_dim-128 kernel set (fa_set_kernel_policy)")
     a = ap.parse_args()
+    from flash_attn_turing import capi
+    capi.set_kernel_policy({"auto": capi.POLICY_AUTO, "mfma16": capi.POLICY_MFMA16, "mfma32": capi.POLICY_MFMA32}[a.policy])
+    print(f"policy {a.policy}: d128 kernels at 4096 non-causal:", [capi.kernel_name(st, 2, 4096, 4096, 16, 128, False) for st in ("fwd", "dq", "dkdv")], flush=True)
     dev = torch.device("cuda:0")
     bad = 0
     for (b, sq, sk, h, hk, d, dt, causal) in SHAPES:
