@@ -16,7 +16,13 @@
 namespace fa {
 
 #ifndef FA_KV16_VREG
-#define FA_KV16_VREG 1        // k-steps (of 32 d) of V held in registers next to all 4 of K
+#define FA_KV16_VREG(CAUSAL) ((CAUSAL) ? 1 : 0)      // k-steps (of 32 d) of V held in registers next to all 4 of K: whatever leaves the instance's tile
+#endif                                               // loop without a spill (a scratch reload per tile cost the non-causal instance 7 %)
+#ifndef FA_KV16_TOGGLE
+#define FA_KV16_TOGGLE 1      // ring-slot addressing: per-lane base registers toggled once per tile (13 VALU) instead of base + slot offset per read (34)
+#endif
+#ifndef FA_KV16_RV
+#define FA_KV16_RV 0          // (with the toggle) V row reads through their own absolute base registers: 4 registers for 6 address adds
 #endif
 #ifndef FA_KV16_PF
 #define FA_KV16_PF 4          // transposed fragments in flight in the dV / dK phase (3: one spill op per tile in the causal instances; 2-4 time the same)
@@ -117,6 +123,24 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 #pragma unroll
     for (int db = 0; db < DB; ++db) tr_rd[db] = lds_tile_off<D>(4 * pi2_g + (n16 >> 2), 2 * db + ((n16 & 3) >> 1)) + 8 * (n16 & 1);
     const float c = p.scale_log2e;
+#if FA_KV16_TOGGLE
+    // Q / dO ring reads as absolute LDS addresses of ring slot 0 with everything wave- or lane-dependent folded in; a read is base register +
+    // immediate (dO = Q + 2 * TILEB), and the registers move to the other slot by flipping ONE address bit per tile: the slots are TILEB =
+    // 2^14 apart and every offset inside a tile stays below that.  Same for the statistics ring (2^9 apart).
+    static_assert(TILEB == (1 << 14) && OFF_Q % (2 * TILEB) == 0 && OFF_DO == OFF_Q + 2 * TILEB && STATB == (1 << 9) && OFF_STAT % (2 * STATB) == 0, "slot toggle");
+    uint32_t rq[KS], rt[DB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) rq[ks] = lds0 + OFF_Q + row_rd[ks] + (uint32_t)(32 * qh) * ROWB;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) rt[db] = lds0 + OFF_Q + tr_rd[db] + (uint32_t)(32 * qh) * ROWB;
+    uint32_t rs = lds0 + OFF_STAT + (uint32_t)(32 * qh + 4 * pi2_g) * 4;
+#if FA_KV16_RV
+    uint32_t rv[KS];                                         // V rows of this wave's key block (no ring: constant)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) rv[ks] = lds0 + OFF_V + row_rd[ks] + (uint32_t)(kb * 32) * ROWB;
+#endif
+    auto at = [](uint32_t a) __attribute__((always_inline)) { return (const FA_LDS char*)(uintptr_t)a; };
+#endif
 
     f32x4 dkacc[DB][2], dvacc[DB][2];                     // dK^T / dV^T: d rows 16*db + 4*g + r, key column kc
 #pragma unroll
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     __syncthreads();
 
     // B operands that never change: this wave's K fragments (all 4 k-steps, both key columns) and the first VREG k-steps of V
-    constexpr int VREG = FA_KV16_VREG < KS ? FA_KV16_VREG : KS;
+    constexpr int VREG = FA_KV16_VREG(CAUSAL) < KS ? FA_KV16_VREG(CAUSAL) : KS;
     u32x4 kreg[KS][2], vreg[VREG > 0 ? VREG : 1][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -209,18 +233,33 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
             for (int kc = 0; kc < 2; ++kc) thr[kc] = (n0 + key_loc + 16 * kc) - (mh + 4 * pi2_g + delta);
             f32x4 nd4[2], nl4[2];                           // -D and -LSE*log2(e) of this lane's query rows of block i
 #pragma unroll
-            for (int i = 0; i < 2; ++i) nd4[i] = *(const FA_LDS f32x4*)(sbuf + kKvBlockM * 4 + (32 * qh + 16 * i + 4 * pi2_g) * 4);
+            for (int i = 0; i < 2; ++i)
+#if FA_KV16_TOGGLE
+                nd4[i] = *(const FA_LDS f32x4*)(at(rs) + kKvBlockM * 4 + 16 * i * 4);
+#else
+                nd4[i] = *(const FA_LDS f32x4*)(sbuf + kKvBlockM * 4 + (32 * qh + 16 * i + 4 * pi2_g) * 4);
+#endif
             f32x4 sacc[2][2], dpacc[2][2];                  // [query block i][key column kc]
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 u32x4 qa[2], da[2], vf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+#if FA_KV16_TOGGLE
+                    qa[i] = lds_read16(at(rq[ks]), 16 * i * ROWB);
+                    da[i] = lds_read16(at(rq[ks]), 2 * TILEB + 16 * i * ROWB);
+#else
                     qa[i] = lds_read16(qbuf, row_rd[ks] + (32 * qh + 16 * i) * ROWB);
                     da[i] = lds_read16(dobuf, row_rd[ks] + (32 * qh + 16 * i) * ROWB);
+#endif
                 }
 #pragma unroll
-                for (int kc = 0; kc < 2; ++kc) vf[kc] = ks < VREG ? vreg[ks < VREG ? ks : 0][kc] : lds_read16(vtile, row_rd[ks] + (kb * 32 + 16 * kc) * ROWB);
+                for (int kc = 0; kc < 2; ++kc)
+#if FA_KV16_TOGGLE && FA_KV16_RV
+                    vf[kc] = ks < VREG ? vreg[ks < VREG ? ks : 0][kc] : lds_read16(at(rv[ks]), 16 * kc * ROWB);
+#else
+                    vf[kc] = ks < VREG ? vreg[ks < VREG ? ks : 0][kc] : lds_read16(vtile, row_rd[ks] + (kb * 32 + 16 * kc) * ROWB);
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -232,7 +271,12 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
             if (more && qh == 1) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
             if (more) pf_advance();
 #pragma unroll
-            for (int i = 0; i < 2; ++i) nl4[i] = *(const FA_LDS f32x4*)(sbuf + (32 * qh + 16 * i + 4 * pi2_g) * 4);
+            for (int i = 0; i < 2; ++i)
+#if FA_KV16_TOGGLE
+                nl4[i] = *(const FA_LDS f32x4*)(at(rs) + 16 * i * 4);
+#else
+                nl4[i] = *(const FA_LDS f32x4*)(sbuf + (32 * qh + 16 * i + 4 * pi2_g) * 4);
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -265,9 +309,15 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
             constexpr int NST = 2 * DB, PF = FA_KV16_PF;            // step j = (db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
             auto rd_frag = [&](int j) {
                 const int db = j >> 1;
+#if FA_KV16_TOGGLE
+                const uint32_t o = (j & 1) ? 0u : 2u * TILEB;
+                const u32x2 a0 = lds_read_tr8(at(rt[db]), o);
+                const u32x2 a1 = lds_read_tr8(at(rt[db]), o + 16 * ROWB);
+#else
                 FA_LDS char* src = (j & 1) ? qbuf : dobuf;
                 const u32x2 a0 = lds_read_tr8(src, tr_rd[db] + (32 * qh) * ROWB);
                 const u32x2 a1 = lds_read_tr8(src, tr_rd[db] + (32 * qh + 16) * ROWB);
+#endif
                 return u32x4{a0.x, a0.y, a1.x, a1.y};
             };
             u32x4 frag[NST];
@@ -286,6 +336,14 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
         if (more && wave < 2) store_stat(st_next, buf ^ 1);
         asm volatile("" :: "v"(st_next));               // consumed on every path: hipcc never has to guard the register at the loop top
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
+#if FA_KV16_TOGGLE
+        // on to the other ring slot (inline asm: hipcc would otherwise re-derive the addresses from `buf` and put the adds back)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(rq[ks]) : "s"((uint32_t)TILEB));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(rt[db]) : "s"((uint32_t)TILEB));
+        asm volatile("v_xor_b32 %0, %1, %0" : "+v"(rs) : "s"((uint32_t)STATB));
+#endif
         __syncthreads();
     }
 
