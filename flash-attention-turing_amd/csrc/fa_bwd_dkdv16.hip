@@ -28,16 +28,24 @@ namespace fa {
 #define FA_KV16_PF 4          // transposed fragments in flight in the dV / dK phase (3: one spill op per tile in the causal instances; 2-4 time the same)
 #endif
 
+#ifndef FA_KV16_NOP_ONCE
+#define FA_KV16_NOP_ONCE 1    // the VALU -> MFMA source hazard of the asm-issued dV / dK MFMAs (P / dS come straight from v_cvt_pk) is padded once, in
+#endif                        // front of the phase, instead of with an s_nop in front of each of its 32 MFMAs: -0.2..-0.8 %
+#if FA_KV16_NOP_ONCE
+#define FA_KV16_NOP ""
+#else
+#define FA_KV16_NOP "s_nop 1\n\t"
+#endif
 template <typename T>
 struct LP16;
 template <>
 struct LP16<_Float16> {
     // accumulate into the accumulator half of the register file (see LP<T>::mfma_agpr); s_nop 1: a / b may have just been written by VALU
-    static FA_DEV void mfma_agpr(f32x4& acc, u32x4 a, u32x4 b) { asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); }
+    static FA_DEV void mfma_agpr(f32x4& acc, u32x4 a, u32x4 b) { asm(FA_KV16_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); }
 };
 template <>
 struct LP16<__bf16> {
-    static FA_DEV void mfma_agpr(f32x4& acc, u32x4 a, u32x4 b) { asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); }
+    static FA_DEV void mfma_agpr(f32x4& acc, u32x4 a, u32x4 b) { asm(FA_KV16_NOP "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); }
 };
 
 template <typename T, bool CAUSAL>
@@ -323,6 +331,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
             u32x4 frag[NST];
 #pragma unroll
             for (int j = 0; j < PF; ++j) frag[j] = rd_frag(j);
+#if FA_KV16_NOP_ONCE
+            // P / dS were just written by VALU (v_cvt_pk): the MFMAs below are inline asm, the hazard recogniser does not see them read those registers
+            asm volatile("s_nop 3" : "+v"(pfr[0]), "+v"(pfr[1]), "+v"(dsfr[0]), "+v"(dsfr[1]));
+#endif
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
                 if (j + PF < NST) frag[j + PF] = rd_frag(j + PF);
