@@ -781,16 +781,17 @@ hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t s) {
 }
 // head_dim 128 has a second set of kernels, re-tiled for v_mfma_f32_16x16x32 (fa_bwd_dq16.hip, fa_bwd_dkdv16.hip; why: fa_fwd_pp16.hip).
 // Measured against the kernels of this file (profiles/r3_bwd_mfma16_ab.log, three boxes): dQ -1..-6 % without a mask at every length but
-// +1..+4 % under a causal mask; dK/dV -2..-5 % on long launches, +-2 % on short ones.  FA_POLICY_AUTO follows those signs; fa_set_kernel_policy()
+// +1..+4 % under a causal mask; dK/dV -2..-8 % from 1k x 1k on, +-1.5 % at 512.  FA_POLICY_AUTO follows those signs; fa_set_kernel_policy()
 // pins either set.
-constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 24;       // seqlen_q * seqlen_k per head: 4096 x 4096 ...
-constexpr int64_t kKvMfma16MinPairsCausal = (int64_t)1 << 26; // ... 8192 x 8192 under a causal mask (per head, not per launch: fa_fwd_pp.hip says why)
+constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 20;       // seqlen_q * seqlen_k per head: 1024 x 1024, causal or not, since its ring addressing
+                                                              // costs one XOR per base register and tile (profiles/r3_policy_sweep.log, second table:
+                                                              // -2..-8 % from 1k on, +-1.5 % at 512); per head, not per launch: fa_fwd_pp.hip says why
 static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
     const int policy = kernel_policy();
     if (kp.d != 128 || policy == 0) return false;
     if (policy == 1) return true;
     if (!dkdv) return !kp.is_causal;
-    return (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kKvMfma16MinPairsCausal : kKvMfma16MinPairs);
+    return (int64_t)kp.seqlen_q * kp.seqlen_k >= kKvMfma16MinPairs;
 }
 const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv) {
     return dkdv ? (bwd_use_mfma16(kp, true) ? "fa_bwd_dkdv16_kernel" : "fa_bwd_dkdv_kernel") : (bwd_use_mfma16(kp, false) ? "fa_bwd_dq16_kernel" : "fa_bwd_dq_kernel");

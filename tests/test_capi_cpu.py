@@ -32,7 +32,8 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dq16_kernel"
     assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, True) == "fa_bwd_dq_kernel"
     assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dkdv16_kernel"
-    assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 128, False) == "fa_bwd_dkdv_kernel"
+    assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 128, False) == "fa_bwd_dkdv16_kernel"
+    assert capi.kernel_name("dkdv", 4, 512, 512, 32, 128, True) == "fa_bwd_dkdv_kernel"
     # per head, not per launch: a (batch, head) shard gets the kernel of the whole problem
     assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == capi.kernel_name("fwd", 64, 16384, 16384, 64, 128, True) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("dkdv", 1, 8192, 8192, 2, 128, True) == "fa_bwd_dkdv16_kernel"
