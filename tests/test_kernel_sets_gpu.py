@@ -16,6 +16,7 @@ import torch
 
 import _util as U
 import test_attention_gpu as TA
+import test_fuzz_gpu as TF
 import test_properties_gpu as TP
 
 pytestmark = pytest.mark.gpu
@@ -126,6 +127,21 @@ def test_policy_switches_kernels_and_both_agree(gpu, pinned_set):
     with pytest.raises(ValueError):
         capi.set_kernel_policy(7)
     assert capi.set_kernel_policy(capi.POLICY_MFMA16) == capi.POLICY_AUTO
+
+
+@pytest.mark.parametrize("case", range(11))
+def test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case):
+    TF.test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_strided_views_are_bit_identical_to_contiguous(gpu, case):
+    TF.test_strided_views_are_bit_identical_to_contiguous(gpu, case)
+
+
+@pytest.mark.parametrize("case", range(0, 16, 3))
+def test_varlen_random_batches_with_empty_sequences(gpu, case):
+    TF.test_varlen_random_batches_with_empty_sequences(gpu, case)
 
 
 def _other_set_than_default(pinned_set, default_is_mfma16):
