@@ -101,6 +101,21 @@ def test_mfma16_forward_keeps_its_accumulators_in_place(kernels):
     assert seen == 4
 
 
+def test_dkdv16_ring_addresses_are_toggled_not_recomputed(kernels):
+    """fa_bwd_dkdv16: the Q / dO ring slot is a run-time value, and base + slot offset per fragment read was a third of the tile loop's
+    VALU instructions (34 of 101); the base registers are absolute addresses flipped to the other slot by one inline-asm v_xor each per tile
+    (-2..-6 % of the kernel, profiles/r3_bwd_mfma16_ab.log).  hipcc puts the adds back if it can see through the toggle: keep it honest."""
+    seen = 0
+    for (f, name), info in kernels.items():
+        if "fa_bwd_dkdv16_kernel" in name:
+            seen += 1
+            main = max(info["loops"], key=lambda l: l["mfma"])
+            assert main["mfma"] == 64, (name, main["mfma"])
+            assert main["histogram"].get("v_xor_b32", 0) == 13, (name, main["histogram"])              # 4 row + 8 transposed + 1 statistics base
+            assert main["histogram"].get("v_add_u32_e32", 0) <= 14, (name, main["histogram"])
+    assert seen == 4
+
+
 def test_guard_detects_the_known_pathology():
     """the detector must fire on the construct it exists for: the wave-level skip branch around asm-accumulator MFMAs"""
     ks = analyse("fa_bwd.hip", extra_flags=["-DFA_TEST_DKDV_SKIP_BRANCH"])
