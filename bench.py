@@ -697,6 +697,30 @@ def main():
             del et
             torch.cuda.empty_cache()
         extra["d64_b4_s8192_h32_fp16"] = d64
+        # head_dim 128 has two kernel sets (32x32x16 / 16x16x32 MFMA tiles; fa_set_kernel_policy): the two pinned, interleaved in this process, on
+        # the headline forward and on the configs[3] backward - what the default policy's choice is worth ON THIS BOX (it moves by a few %
+        # between boxes of the pool); the policy is back on FA_POLICY_AUTO afterwards
+        import statistics as _st
+        ab = {}
+        for label, (bb, ss, hh, dt_, cz, bw) in {"c3_fwd": (4, 16384, 32, "fp16", True, False), "c4_bwd": (4, 8192, 32, "bf16", False, True)}.items():
+            et = make_inputs(torch, device, bb, ss, hh, hh, 128, dt_, 777, bw)
+            capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], cz)
+            f = ((lambda: capi.mha_bwd(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"], et["dv"], et["dsum"], cz)) if bw
+                 else (lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], cz)))
+            t = {capi.POLICY_MFMA32: [], capi.POLICY_MFMA16: []}
+            for _ in range(5):
+                for pol in t:
+                    capi.set_kernel_policy(pol)
+                    f(); sync()
+                    t[pol].append(event_time_ms(torch, f, 3))
+            capi.set_kernel_policy(capi.POLICY_AUTO)
+            m32, m16 = _st.median(t[capi.POLICY_MFMA32]), _st.median(t[capi.POLICY_MFMA16])
+            stages = ("dq", "dkdv") if bw else ("fwd",)
+            ab[label] = {"ms_mfma_32x32x16": m32, "ms_mfma_16x16x32": m16, "ratio_16_over_32": m16 / m32,
+                         "auto_picks": {st_: capi.kernel_name(st_, bb, ss, ss, hh, 128, cz) for st_ in stages}}
+            del et
+            torch.cuda.empty_cache()
+        extra["kernel_sets_ab"] = ab
         # seqlen sweep of the reference's published chart (README.md:7-16): b4 h32 d128
         for cz in (False, True):
             sweep = {}
