@@ -39,8 +39,29 @@ __all__ = [
     "fwd", "bwd", "varlen_fwd", "varlen_bwd",
     "flash_attn_func", "flash_attn_varlen_func", "FlashAttnFunc", "FlashAttnVarlenFunc",
     "ShardPlan", "plan_shards", "shard_tensor", "LIBRARY_PATH", "EXTENSION_PATH",
+    "set_kernel_policy", "kernel_name",
 ]
 __version__ = "0.1.0"
+
+
+def set_kernel_policy(policy) -> str:
+    """Which of the two head_dim-128 kernel sets serves the launches of this process: "auto" (default: per launch by sequence length and
+    mask), "mfma32" or "mfma16" (C ABI fa_set_kernel_policy; both sets meet the same tolerances, they differ in speed only).  Returns the
+    previous policy's name.  No counterpart in the reference."""
+    from . import capi
+
+    names = {"mfma32": capi.POLICY_MFMA32, "mfma16": capi.POLICY_MFMA16, "auto": capi.POLICY_AUTO}
+    if policy not in names:
+        raise ValueError(f"policy must be one of {sorted(names)}")
+    prev = capi.set_kernel_policy(names[policy])
+    return next(k for k, v in names.items() if v == prev)
+
+
+def kernel_name(stage, batch, seqlen_q, seqlen_k, nheads, head_dim, causal) -> str:
+    """the kernel a launch of this shape goes to under the current policy; stage in {"fwd", "dq", "dkdv"} (C ABI fa_kernel_name)"""
+    from . import capi
+
+    return capi.kernel_name(stage, batch, seqlen_q, seqlen_k, nheads, head_dim, causal)
 
 
 def abi_version() -> int:

@@ -41,6 +41,17 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.lib().fa_kernel_name(9, 1, 1, 1, 1, 128, 0) == b""
 
 
+def test_package_level_policy_helpers():
+    import flash_attn_turing as F
+
+    assert F.set_kernel_policy("mfma16") == "auto"
+    assert F.kernel_name("fwd", 1, 128, 128, 1, 128, False) == "fa_fwd_pp16_kernel"
+    assert F.set_kernel_policy("auto") == "mfma16"
+    assert F.kernel_name("fwd", 1, 128, 128, 1, 128, False) == "fa_fwd_pp_kernel"
+    with pytest.raises(ValueError):
+        F.set_kernel_policy("fastest")
+
+
 def test_flops_and_bytes_match_survey_figures():
     L = capi.lib()
     # C2 1.0995e12, C3 non-causal 1.7592e13
