@@ -113,7 +113,7 @@ def build_torch_module(force=False):
     from torch.utils import cpp_extension as ce
 
     src = os.path.join(CSRC, "flash_api.cpp")
-    stamp = _digest([src, os.path.join(INCLUDE, "flash_attn_gfx950.h")], torch.__version__)
+    stamp = _digest([src, os.path.join(INCLUDE, "flash_attn_gfx950.h")], torch.__version__ + " rpath:$ORIGIN,$ORIGIN/../csrc")
     if not force and not _stale(EXT_PATH, stamp):
         print("[build] flash_attn_turing/_C.so up to date")
         return EXT_PATH
@@ -130,7 +130,7 @@ def build_torch_module(force=False):
             "-L", tlib, "-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
             "-L", CSRC, "-l:" + LIB_NAME,
             "-L", os.path.join(rocm, "lib"), "-lamdhip64",
-            "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+            "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(rocm, "lib")]      # $ORIGIN: installed layout (setup.py)
     _run(cmd)
     _write_stamp(EXT_PATH, stamp)
     print(f"[build] flash_attn_turing/_C.so built in {time.time() - t0:.1f}s")

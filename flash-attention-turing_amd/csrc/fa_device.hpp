@@ -91,6 +91,8 @@ struct LP<_Float16> {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
     }
     static FA_DEV float to_float(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+    static constexpr uint32_t kOnes2 = 0x3C003C00u;      // two packed 1.0
+    static constexpr uint32_t kBits64 = 0x5400u;         // 64.0
 };
 
 template <>
@@ -127,6 +129,8 @@ struct LP<__bf16> {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));  // v_cvt_pk_bf16_f32 (RN)
     }
     static FA_DEV float to_float(uint16_t bits) { return __builtin_bit_cast(float, (uint32_t)bits << 16); }
+    static constexpr uint32_t kOnes2 = 0x3F803F80u;
+    static constexpr uint32_t kBits64 = 0x4280u;
 };
 
 // ---- buffer (SRD) addressing -----------------------------------------------------------------
@@ -274,6 +278,13 @@ FA_DEV float max_four_groups(float x) {
     uint32_t u = __builtin_bit_cast(uint32_t, x);
     auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     return max_both_halves(fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1])));
+}
+
+// element-wise IEEE maximum of three packed 16-bit float pairs (NaN propagates); used on bit patterns, see fa_fwd_pp16.hip
+FA_DEV uint32_t pk_max3_f16_bits(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 FA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32

@@ -25,13 +25,18 @@ constexpr int kFwdThreads = 512;
 constexpr int kFwdBlockM = 256;
 constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PP_MIN_WAVES(D, BN) 2
-// FA_PP16_FOLD_MAX = 1 (measured, NOT shipped): Q pre-scaled by log2(e)/sqrt(d) and rounded back to fp16 / bf16, every score block's MFMA
-// chain started from -running_max instead of 0, so that P = exp2(score) with no multiply-subtract per score (a quarter of the softmax
-// VALU work).  +5 % at the fp16 BASELINE shapes, nothing at bf16 - and the extra rounding of Q moves LSE by 2-5e-4 (fp16) / 2-5e-3 (bf16) on
-// N(0,1) inputs, 100x that on inputs 30x larger, where the exact kernels agree with fp32 math to 1e-6: the north star asks for LSE within
-// fp32 tolerance, so the exact form stays (profiles/r3_fwd_mfma16_ab.log).
-#ifndef FA_PP16_FOLD_MAX
-#define FA_PP16_FOLD_MAX 0
+// FA_PP16_FOLD_MAX (round 3: Q pre-scaled by log2(e)/sqrt(d), score chains started from -running_max; +5 % fp16) was measured and rejected
+// for what rounding Q * scale does to LSE (profiles/r3_fwd_mfma16_ab.log); the code left the source in round 4 (history: c6d38fe).
+//
+// FA_PP16_MFMA_ROWSUM (round 4): the softmax row sum l leaves the VALU.  One extra MFMA per 32-key chunk and query column multiplies an
+// all-ones A operand with the P^T fragment that feeds P.V anyway: every row of the 16 x 16 result is the chunk's column sum, already
+// reduced over the four lane groups (+4 MFMAs on 64 per tile, -32 v_add_f32 per wave and tile).  The optimistic pass is then guarded by
+// the largest packed P of the lane (v_pk_maximum3_f16 on the B-operand registers, 11 VALU) instead of the VALU partial sum.
+// l is then the sum of the ROUNDED P values (fp32 accumulation in the matrix pipe): O = sum(round(P) V) / sum(round(P)) is a proper convex
+// combination, and LSE carries the rounding noise of P: |dLSE| <= 2^-12 worst case (fp16), ~1.4e-4 / sqrt(effective keys) typical.
+//   0 = off (VALU sums), 1 = fp16 only (default: bf16's 2^-9 would show in LSE on rows dominated by one key), 2 = both dtypes.
+#ifndef FA_PP16_MFMA_ROWSUM
+#define FA_PP16_MFMA_ROWSUM 1
 #endif
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
@@ -44,6 +49,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     constexpr int TILEB = kFwdBlockN * ROWB;
     constexpr int RING = 3;
     constexpr int RINGB = 2 * RING * TILEB, STAGEB = kFwdBlockM * ROWB;     // D = 128: 96 KiB + 64 KiB = all 160 KiB of the CU
+    constexpr bool ML = FA_PP16_MFMA_ROWSUM == 2 || (FA_PP16_MFMA_ROWSUM == 1 && std::is_same<T, _Float16>::value);      // row sums through the matrix pipe
     __shared__ __attribute__((aligned(16))) char smem_raw[RINGB + STAGEB];
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
     FA_LDS char* kring = smem;
@@ -151,18 +157,6 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)(q_row_a + 16 * qb) * q_rowb + (4 * ks + pi_g) * 16);
-#if FA_PP16_FOLD_MAX
-        // Q' = round(Q * log2(e) / sqrt(d)): the scores leave the MFMAs in the exponent's units (see softmax_step)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t w = qf[ks][qb][e];
-                    qf[ks][qb][e] = LP<T>::pack2(LP<T>::to_float((uint16_t)(w & 0xffffu)) * c, LP<T>::to_float((uint16_t)(w >> 16)) * c);
-                }
-#endif
     }
 
     f32x4 oacc[DB][2];                                    // O^T: d rows 16*db + 4*g + r, query column qb
@@ -170,10 +164,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if FA_PP16_FOLD_MAX
-    f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // -m_run, the C operand every score block starts from
-#endif
     float m_run[2] = {kNegBig, kNegBig}, l_run[2] = {0.f, 0.f};      // per query column; l_run is this lane's PARTIAL row sum (its 4 of every 16 keys)
+    // ML: l as a 16 x 16 MFMA tile per query column, ones(16 x 32) * P^T: all four registers of every lane hold the column's FULL row sum
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    u32x4 ones_a = {LP<T>::kOnes2, LP<T>::kOnes2, LP<T>::kOnes2, LP<T>::kOnes2};
+    if constexpr (ML) asm volatile("" : "+v"(ones_a));           // (a register-resident constant: MFMA operands cannot be literals)
 
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
     auto dma_k_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
@@ -218,16 +213,15 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             constexpr int db = j % DB, cch = j / DB;
             LP<T>::mfma16_acc(oacc[db][0], fr, pf[cch][0]);          // (this accumulator's previous MFMA is DB fragments = 2 * DB MFMAs back)
             LP<T>::mfma16_acc(oacc[db][1], fr, pf[cch][1]);
+            if constexpr (ML && db == DB - 1) {                      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
+                LP<T>::mfma16_acc(lacc[0], ones_a, pf[cch][0]);
+                LP<T>::mfma16_acc(lacc[1], ones_a, pf[cch][1]);
+            }
         } else {
             constexpr int i = j - NPV, ks = i / NKB, kb = i % NKB;
             if constexpr (ks == 0) {                               // (previous MFMA on this accumulator: NKB fragments back)
-#if FA_PP16_FOLD_MAX
-                LP<T>::mfma16_init(sacc[kb][0], fr, qf[ks][0], negm[0]);
-                LP<T>::mfma16_init(sacc[kb][1], fr, qf[ks][1], negm[1]);
-#else
                 LP<T>::mfma16_zero(sacc[kb][0], fr, qf[ks][0]);
                 LP<T>::mfma16_zero(sacc[kb][1], fr, qf[ks][1]);
-#endif
             } else {
                 LP<T>::mfma16_acc(sacc[kb][0], fr, qf[ks][0]);
                 LP<T>::mfma16_acc(sacc[kb][1], fr, qf[ks][1]);
@@ -300,70 +294,6 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         // running max is still -1e30) the wave reduces the row maxima; if some row outgrew its running max by more than 2^kPpDeferLog2 the max is
         // refreshed, l and O are rescaled and the SAME pass runs once more (now every term is <= 1); if not, the pass already holds exactly
         // what the exact path would compute.
-#if FA_PP16_FOLD_MAX
-        // The scores arrive as x = s * log2(e)/sqrt(d) - m_run (Q is pre-scaled, the MFMA chain starts from -m_run): P = exp2(x), no
-        // multiply-subtract per score.  `dm` is what the running max has moved by since the MFMAs of THIS tile were issued: 0 on the hot path.
-        float dm[2] = {0.f, 0.f};
-        if constexpr (decltype(maybe_first)::value) {
-            // tile 0 meets an empty running max (its scores started from 0): seed it with the tile's row maxima; no O or l to rescale yet
-            if (u == 0) {
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    float mx = sacc[0][qb][0];
-#pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kb][qb][r]);
-                    m_run[qb] = fmaxf(kNegBig, max4(mx));      // (a row with no visible key keeps the floor: it never sees one later either)
-                    dm[qb] = m_run[qb];
-                    negm[qb] = f32x4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
-                }
-            }
-        }
-        float ps[2];
-        for (int attempt = 0;; ++attempt) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                ps[qb] = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
-                    const float p0 = fast_exp2(sacc[kb][qb][0] - dm[qb]), p1 = fast_exp2(sacc[kb][qb][1] - dm[qb]);
-                    const float p2 = fast_exp2(sacc[kb][qb][2] - dm[qb]), p3 = fast_exp2(sacc[kb][qb][3] - dm[qb]);
-                    ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3;
-                    if (kb & 1) { pf[kb >> 1][qb].z = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].w = LP<T>::pack2(p2, p3); }
-                    else { pf[kb >> 1][qb].x = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].y = LP<T>::pack2(p2, p3); }
-                }
-            }
-            if (attempt != 0 || __builtin_amdgcn_ballot_w64(!(ps[0] <= 64.0f && ps[1] <= 64.0f)) == 0) break;
-            float mx[2];
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                mx[qb] = sacc[0][qb][0];
-#pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx[qb] = fmaxf(mx[qb], sacc[kb][qb][r]);
-                mx[qb] = max4(mx[qb]) - dm[qb];                 // how far the tile's row max stands above the running max
-            }
-            // (one decision for both query columns: refreshing a column that did not need it is exact too)
-            if (__builtin_amdgcn_ballot_w64(mx[0] > kPpDeferLog2 || mx[1] > kPpDeferLog2) == 0) break;
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const float up = fmaxf(mx[qb], 0.f);
-                const float alpha = fast_exp2(-up);
-                m_run[qb] += up;
-                dm[qb] += up;
-                negm[qb] = f32x4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
-                l_run[qb] *= alpha;
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) oacc[db][qb][r] *= alpha;
-            }
-        }
-        l_run[0] += ps[0];
-        l_run[1] += ps[1];
-#else
         // Tile 0 meets an empty running max: its first pass would always be thrown away, so the running max is seeded with the tile's row
         // maxima (no O or l to rescale yet) and the pass below stands at once.
         if constexpr (decltype(maybe_first)::value) {
@@ -380,7 +310,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             }
         }
         float ps[2];
-        for (int attempt = 0;; ++attempt) {
+        // exponentials of the tile against the running max as it stands -> P^T fragments; returns "some P above 2^kPpDeferLog2, or not finite"
+        auto pass = [&]() __attribute__((always_inline)) -> bool {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const float mc0 = m_run[qb] * c;
@@ -389,16 +320,62 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 for (int kb = 0; kb < NKB; ++kb) {
                     const float p0 = fast_exp2(__builtin_fmaf(sacc[kb][qb][0], c, -mc0)), p1 = fast_exp2(__builtin_fmaf(sacc[kb][qb][1], c, -mc0));
                     const float p2 = fast_exp2(__builtin_fmaf(sacc[kb][qb][2], c, -mc0)), p3 = fast_exp2(__builtin_fmaf(sacc[kb][qb][3], c, -mc0));
-                    ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3;
+                    if constexpr (!ML) { ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3; }
                     if (kb & 1) { pf[kb >> 1][qb].z = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].w = LP<T>::pack2(p2, p3); }
                     else { pf[kb >> 1][qb].x = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].y = LP<T>::pack2(p2, p3); }
                 }
             }
-#if FA_PP16_PIN_PF
+            if constexpr (ML) {
+                // largest packed P of the lane, both query columns: positive fp16 / bf16 bit patterns order like unsigned integers, and
+                // v_pk_maximum3_f16 (IEEE maximum: NaN wins) on bf16 bits is monotone as long as they read as finite fp16, i.e. below 2^121;
+                // anything above, Inf and NaN come out as a pattern above kBits64 as well.
+                static_assert(NC == 2, "guard written for two 32-key chunks per tile");
+                uint32_t t0 = pk_max3_f16_bits(pf[0][0].x, pf[0][0].y, pf[0][0].z), t1 = pk_max3_f16_bits(pf[0][1].x, pf[0][1].y, pf[0][1].z);
+                t0 = pk_max3_f16_bits(t0, pf[0][0].w, pf[1][0].x); t1 = pk_max3_f16_bits(t1, pf[0][1].w, pf[1][1].x);
+                t0 = pk_max3_f16_bits(t0, pf[1][0].y, pf[1][0].z); t1 = pk_max3_f16_bits(t1, pf[1][1].y, pf[1][1].z);
+                t0 = pk_max3_f16_bits(t0, pf[1][0].w, t1);
+                t0 = pk_max3_f16_bits(t0, pf[1][1].w, pf[1][1].w);
+                const uint32_t both = max(t0, t0 << 16);          // top half = the larger of the two packed values
+                return both > ((LP<T>::kBits64 << 16) | 0xffffu);
+            } else {
+                return !(ps[0] <= 64.0f && ps[1] <= 64.0f);
+            }
+        };
+        if constexpr (ML) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pass()) != 0, 0)) {
+                float mx[2];
 #pragma unroll
-            for (int cc = 0; cc < NC; ++cc) { asm volatile("" : "+v"(pf[cc][0])); asm volatile("" : "+v"(pf[cc][1])); }
-#endif
-            if (attempt != 0 || __builtin_amdgcn_ballot_w64(!(ps[0] <= 64.0f && ps[1] <= 64.0f)) == 0) break;
+                for (int qb = 0; qb < 2; ++qb) {
+                    mx[qb] = sacc[0][qb][0];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx[qb] = fmaxf(mx[qb], sacc[kb][qb][r]);
+                    mx[qb] = max4(mx[qb]);
+                }
+                // (one decision for both query columns: refreshing a column that did not need it is exact too; a NaN / Inf score fails
+                // both tests and the pass stands with its NaN)
+                if (__builtin_amdgcn_ballot_w64((mx[0] - m_run[0]) * c > kPpDeferLog2 || (mx[1] - m_run[1]) * c > kPpDeferLog2) != 0) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        const float m_new = fmaxf(m_run[qb], mx[qb]);
+                        const float alpha = fast_exp2((m_run[qb] - m_new) * c);
+                        m_run[qb] = m_new;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
+#pragma unroll
+                        for (int db = 0; db < DB; ++db)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) oacc[db][qb][r] *= alpha;
+                    }
+                    (void)pass();
+                }
+            }
+            return;
+        }
+        for (int attempt = 0;; ++attempt) {
+            const bool over = pass();
+            if (attempt != 0 || __builtin_amdgcn_ballot_w64(over) == 0) break;
             float mx[2];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
@@ -425,7 +402,6 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         }
         l_run[0] += ps[0];
         l_run[1] += ps[1];
-#endif
     };
     auto advance_ring = [&]() __attribute__((always_inline)) {
         ring_um1 = ring_u;
@@ -444,10 +420,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         const int rows_here = rows_of(t);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const float l_tot = sum4(l_run[qb]);
+            if constexpr (ML) asm volatile("" : "+v"(lacc[qb]));
+            const float l_tot = ML ? lacc[qb][0] : sum4(l_run[qb]);
             // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
             const float inv = l_tot != 0.f ? fast_rcp(l_tot) : 0.f;
-            const float lse = l_tot != 0.f ? (m_run[qb] * (FA_PP16_FOLD_MAX ? 1.0f : c) + fast_log2(l_tot)) * kLn2 : 0.f;
+            const float lse = l_tot != 0.f ? (m_run[qb] * c + fast_log2(l_tot)) * kLn2 : 0.f;
             const int row = q_row_a + 16 * qb;
             if (g == 0 && row < rows_here) lse_bh[t * kFwdBlockM + row] = lse;
 #pragma unroll

@@ -13,14 +13,16 @@ import os as _os
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 _CSRC = _os.path.join(_os.path.dirname(_HERE), "csrc")
-LIBRARY_PATH = _os.path.join(_CSRC, "libflash_attn_gfx950.so")
+# in-tree build: ../csrc/libflash_attn_gfx950.so; installed (`pip install .`, setup.py): the library ships inside the package
+LIBRARY_PATH = next((c for c in (_os.path.join(_HERE, "libflash_attn_gfx950.so"), _os.path.join(_CSRC, "libflash_attn_gfx950.so")) if _os.path.exists(c)),
+                    _os.path.join(_CSRC, "libflash_attn_gfx950.so"))
 EXTENSION_PATH = _os.path.join(_HERE, "_C.so")
 
 if not _os.path.exists(LIBRARY_PATH) or not _os.path.exists(EXTENSION_PATH):
     raise ImportError(
         "flash_attn_turing: compiled HIP extension not found "
         f"({LIBRARY_PATH if not _os.path.exists(LIBRARY_PATH) else EXTENSION_PATH}). "
-        "Run `python flash-attention-turing_amd/build.py` (needs hipcc); there is no CPU/PyTorch fallback."
+        "Run `python flash-attention-turing_amd/build.py` or `pip install .` (needs hipcc); there is no CPU/PyTorch fallback."
     )
 
 import torch as _torch  # noqa: E402,F401  (libtorch must be loaded before _C)

@@ -10,8 +10,16 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libflash_attn_gfx950.so")
-HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "flash_attn_gfx950.h")
+
+
+def _first_existing(*candidates):
+    return next((c for c in candidates if os.path.exists(c)), candidates[-1])
+
+
+# installed package (setup.py ships library and header inside it) first, then the in-tree build
+LIBRARY_PATH = _first_existing(os.path.join(_HERE, "libflash_attn_gfx950.so"), os.path.join(os.path.dirname(_HERE), "csrc", "libflash_attn_gfx950.so"))
+HEADER_PATH = _first_existing(os.path.join(_HERE, "include", "flash_attn_gfx950.h"),
+                              os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "flash_attn_gfx950.h"))
 
 FA_FP16, FA_BF16 = 0, 1
 FA_OK = 0

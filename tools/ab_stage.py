@@ -19,11 +19,14 @@ CONFIGS = {
     "c4 bf16 d128 8k": (4, 8192, 32, 32, 128, BF16, False),
     "bf16 d128 8k causal": (4, 8192, 32, 32, 128, BF16, True),
     "c3 fp16 d128 16k causal": (4, 16384, 32, 32, 128, F16, True),
+    "c5shard fp16 d128 16k": (4, 16384, 32, 32, 128, F16, False),
     "c2 fp16 d128 4k": (4, 4096, 32, 32, 128, F16, False),
     "fp16 d128 2k": (4, 2048, 32, 32, 128, F16, False),
     "fp16 d128 1k": (4, 1024, 32, 32, 128, F16, False),
     "fp16 d128 512": (4, 512, 32, 32, 128, F16, False),
     "fp16 d128 1k causal": (4, 1024, 32, 32, 128, F16, True),
+    "fp16 d128 2k causal": (4, 2048, 32, 32, 128, F16, True),
+    "fp16 d128 512 causal": (4, 512, 32, 32, 128, F16, True),
     "fp16 d64 8k": (4, 8192, 32, 32, 64, F16, False),
     "fp16 d64 8k causal": (4, 8192, 32, 32, 64, F16, True),
     "bf16 d128 8k mqa causal": (4, 8192, 32, 1, 128, BF16, True),
