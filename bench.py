@@ -80,6 +80,11 @@ class Dist:
         self.want = want
         self.group = None          # None = default (gloo) group
         self.on_device = False
+        # the backend of the subgroup `want == "nccl"` asks for.  FA_BENCH_SUBGROUP_BACKEND=gloo stands a CPU process group in for RCCL so
+        # that the SUCCESS branch of the adoption (every rank initialised -> subgroup adopted -> barrier and reductions go through it) can
+        # be driven without GPUs (tests/test_dist_cpu.py); the subgroup's tensors then live on the CPU.
+        self.sub_backend = os.environ.get("FA_BENCH_SUBGROUP_BACKEND", "nccl")
+        self.sub_calls = {"barrier": 0, "all_reduce": 0}      # collectives that went through the adopted subgroup
         self.comm_backend = "none (single process)"
         # FA_BENCH_FORCE_PG=1: create the process groups even at world size 1, so that the real init / barrier / all_reduce
         # calls of the N > 1 path can be exercised on a 1-GPU box (RCCL refuses two ranks on one device)
@@ -103,11 +108,13 @@ class Dist:
 
         ok, why = 1.0, ""
         grp = None
+        on_gpu = self.sub_backend == "nccl"
         try:
-            grp = self.dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
-            t = torch.ones(1, dtype=torch.float64, device=device)
+            grp = self.dist.new_group(backend=self.sub_backend, timeout=datetime.timedelta(seconds=180))
+            t = torch.ones(1, dtype=torch.float64, device=device if on_gpu else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=grp)
-            torch.cuda.synchronize(device)
+            if on_gpu:
+                torch.cuda.synchronize(device)
             if int(t.item()) != self.world:
                 ok, why = 0.0, f"nccl all_reduce returned {t.item()} for world {self.world}"
         except Exception as e:  # noqa: BLE001 - reported in the JSON, the harness continues on gloo
@@ -115,7 +122,8 @@ class Dist:
         agree = torch.tensor([ok], dtype=torch.float64)
         self.dist.all_reduce(agree, op=self.dist.ReduceOp.MIN)      # default (gloo) group: every rank learns the verdict
         if agree.item() >= 1.0:
-            self.group, self.on_device, self.comm_backend = grp, True, "nccl (RCCL)"
+            self.group, self.on_device = grp, on_gpu
+            self.comm_backend = "nccl (RCCL)" if on_gpu else f"{self.sub_backend} subgroup standing in for nccl (FA_BENCH_SUBGROUP_BACKEND)"
         else:
             self.comm_backend = "gloo (nccl unavailable" + (f": {why}" if why else " on another rank") + ")"
         return self.comm_backend
@@ -128,15 +136,19 @@ class Dist:
     def barrier(self, device=None):
         if not self.enabled:
             return
+        if self.group is not None:
+            self.sub_calls["barrier"] += 1
         if self.on_device:
             self.dist.barrier(group=self.group, device_ids=[device.index if device is not None else self.local_rank])
         else:
-            self.dist.barrier()
+            self.dist.barrier(group=self.group)
 
     def _reduce(self, x, op, device):
         if not self.enabled:
             return x
         t = self._tensor(x, device)
+        if self.group is not None:
+            self.sub_calls["all_reduce"] += 1
         self.dist.all_reduce(t, op=op, group=self.group)
         return float(t.item())
 
@@ -151,17 +163,22 @@ class Dist:
             self.dist.destroy_process_group()
 
 
-def timed_region(step_fn, steps, warmup, dist, sync_fn, device=None):
+def timed_region(step_fn, steps, warmup, dist, sync_fn, device=None, events=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
-    sides; returns (max-over-ranks wall seconds for the K steps, local wall seconds)."""
+    sides; returns (max-over-ranks wall seconds for the K steps, local wall seconds).  `events` = (start, end) HIP events recorded on the
+    launch stream directly around the K steps: the device-side duration of the SAME launches the wall clock brackets (roofline.achieved)."""
     for _ in range(warmup):
         step_fn()
     sync_fn()
     dist.barrier(device)
     sync_fn()
     t0 = time.perf_counter()
+    if events is not None:
+        events[0].record()
     for _ in range(steps):
         step_fn()
+    if events is not None:
+        events[1].record()
     sync_fn()
     dist.barrier(device)
     sync_fn()
@@ -439,7 +456,7 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     A.attn_fwd(q, k, v, causal=True, round_mode=A.ROUND_FP16)
     dt = time.perf_counter() - t0
-    out = {
+    port = {
         "value": fwd_flops(b, s, s, h, d, True) / dt / 1e12, "unit": "TFLOP/s", "cores": A.num_threads(), "kind": "port",
         "sample": f"oracle/attn_oracle.c forward, b={b} h={h} seq={s} d={d} fp16-rounded causal "
                   f"(same per-head problem as the headline, shortened from seq 16384), {dt:.1f} s",
@@ -456,9 +473,23 @@ def cpu_baseline(args):
         for _ in range(n):
             torch.nn.functional.scaled_dot_product_attention(qt, kt, vt)
         dt = (time.perf_counter() - t0) / n
-    out["sdpa_math_cpu"] = {"config": "b1 s512 h4 d128 fp32 non-causal (BASELINE configs[0])", "ms": dt * 1e3,
-                            "tflops": fwd_flops(1, 512, 512, 4, 128, False) / dt / 1e12,
-                            "threads": torch.get_num_threads(), "host_cores": os.cpu_count()}
+        # a bounded ladder towards the GPU shapes (the math path materialises b*h*s*s fp32 scores: 137 GB at the headline shape)
+        ladder = {}
+        for ss, hh in ((1024, 4), (2048, 4), (2048, 32)):
+            ql, kl, vl = (torch.randn(1, hh, ss, 128) for _ in range(3))
+            torch.nn.functional.scaled_dot_product_attention(ql, kl, vl)
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                torch.nn.functional.scaled_dot_product_attention(ql, kl, vl)
+            dl = (time.perf_counter() - t1) / reps
+            ladder[f"b1_h{hh}_s{ss}"] = {"ms": dl * 1e3, "tflops": fwd_flops(1, ss, ss, hh, 128, False) / dl / 1e12}
+    # the baseline the north star names: PyTorch SDPA, CPU, math path, on this node's host cores, in the same run
+    out = {"value": fwd_flops(1, 512, 512, 4, 128, False) / dt / 1e12, "unit": "TFLOP/s", "cores": torch.get_num_threads(), "kind": "sdpa_math_cpu",
+           "host_cores": os.cpu_count(),
+           "sample": f"torch.nn.functional.scaled_dot_product_attention under sdpa_kernel(MATH) on CPU tensors, b1 s512 h4 d128 fp32 non-causal "
+                     f"(BASELINE configs[0]), mean of {n} calls = {dt * 1e3:.2f} ms, {torch.get_num_threads()} torch threads of {os.cpu_count()} host cores",
+           "ladder_same_path": ladder, "oracle_port": port}
     return out
 
 
@@ -482,7 +513,7 @@ def run_fake(args, dist):
 
     def make_point(seq, causal, p):
         # a fake kernel whose time is proportional to the (batch, head) units of the shard it is given
-        per_unit = 2e-5 * (seq / 512.0)
+        per_unit = 8e-5 * (seq / 512.0)      # (5-10 ms per fake launch: long against the sleep jitter of a busy CI box)
         return (lambda: time.sleep(per_unit * p.n_units)), (lambda: time.sleep(per_unit * 4 * 32))
 
     sweep = strong_scaling_sweep(dist, make_point, lambda: None, None, seqs=(512, 1024), causals=(False,))
@@ -490,7 +521,7 @@ def run_fake(args, dist):
         print(json.dumps({"metric": "fake_units_per_s", "value": units * args.steps / wall, "unit": "units/s",
                           "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": wall / args.steps * 1e3, "units_total": units, "local_ms": local * 1e3,
-                          "comm_backend": backend, "extra": {"sweep_strong": sweep}}))
+                          "comm_backend": backend, "subgroup_collectives": dist.sub_calls, "extra": {"sweep_strong": sweep}}))
 
 
 def bwd_rooflines(torch, capi, et, causal, b, s, h, d):
@@ -570,24 +601,42 @@ def main():
 
     sync = lambda: torch.cuda.synchronize(device)
     flops_rank = fwd_flops(b, s, s, h, d, causal) * (3.5 if backward else 1.0)
+    region_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     with PowerSampler(device.index) as sampler:
-        wall, _ = timed_region(step, args.steps, args.warmup, dist, sync, device)
+        wall, _ = timed_region(step, args.steps, args.warmup, dist, sync, device, events=region_events)
         t_reg1 = time.perf_counter()
         power_timed = sampler.summary(t_reg1 - wall, t_reg1, f"the timed region itself ({args.steps} steps, {wall * 1e3:.0f} ms)")
-        # the timed region of the default command is ~0.15 s; a 2 s loop of the same launch gives the sensors time to settle
+        # the timed region of the default command is ~0.15 s; >= 2 s of the same step, every step between its own HIP events, gives the
+        # sensors time to settle and the steady-state figure (median / min) SURVEY 8(d) asks for
         t_s0 = time.perf_counter()
+        sustained_evs = []
         while time.perf_counter() - t_s0 < 2.0:
             for _ in range(10):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 step()
+                e1.record()
+                sustained_evs.append((e0, e1))
             sync()
-        power_sustained = sampler.summary(t_s0 + 0.5, time.perf_counter(), "2 s of back-to-back launches of the same step right after the timed region (first 0.5 s dropped)")
+        t_s1 = time.perf_counter()
+        power_sustained = sampler.summary(t_s0 + 0.5, t_s1, "2 s of back-to-back launches of the same step right after the timed region (first 0.5 s dropped)")
     ms_per_step = wall / args.steps * 1e3
     value = flops_rank * dist.world / (wall / args.steps) / 1e12
+    region_event_ms = region_events[0].elapsed_time(region_events[1]) / args.steps      # device-side ms per step of the timed region
+    import statistics as _stats
+    sus = [a.elapsed_time(b) for a, b in sustained_evs][len(sustained_evs) // 4:]      # (first quarter dropped: the ramp)
+    sustained = {"what": "every step of >= 2 s of back-to-back steps right after the timed region, each between its own HIP events (first quarter dropped)",
+                 "steps": len(sus), "seconds": t_s1 - t_s0, "median_ms": _stats.median(sus), "min_ms": min(sus), "max_ms": max(sus),
+                 "tflops_at_median": flops_rank / _stats.median(sus) / 1e9, "tflops_at_min": flops_rank / min(sus) / 1e9,
+                 "frac_at_median": flops_rank / _stats.median(sus) / 1e9 / PEAK_DENSE_FP16_TFLOPS}
 
-    # dominant-kernel roofline: forward kernel alone, HIP events on the launch stream
+    # dominant-kernel roofline: the forward kernel.  ONE definition: `achieved` = algorithmic FLOPs of a launch over the
+    # kernel's average launch duration, HIP events on the launch stream OVER THE TIMED REGION - for a forward-only workload a step IS one
+    # launch of that kernel, so achieved follows from the same K launches as `value` / `ms_per_step` (they differ by the host-side bracket
+    # only: barrier + synchronize).  A forward+backward workload times its forward launches alone in a loop of the same length.
     fwd_kernel = capi.kernel_name("fwd", b, s, s, h, d, causal)      # the kernel THIS workload's launches go to
     fwd_only = lambda: capi.mha_fwd(t["q"], t["k"], t["v"], t["o"], t["lse"], causal)
-    k_ms = event_time_ms(torch, fwd_only, max(5, args.steps))
+    k_ms = region_event_ms if not backward else event_time_ms(torch, fwd_only, max(5, args.steps))
     k_tflops = fwd_flops(b, s, s, h, d, causal) / (k_ms * 1e-3) / 1e12
     k_dist = launch_time_distribution(torch, fwd_only, max(30, args.steps))
     traffic, traffic_source, prof_digest, prof_commit = hbm_traffic_from_profile(args.workload, fwd_kernel) if dist.rank == 0 else (None, None, None, None)
@@ -599,7 +648,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_profile_library_digest": prof_digest, "traffic_profile_git_commit": prof_commit, "library_source_digest": lib_digest,
                 "profile_matches_library": (prof_digest == lib_digest) if prof_digest else None,
-                "avg_launch_ms": k_ms, "launch_ms_distribution": k_dist,
+                "avg_launch_ms": k_ms, "avg_launch_ms_source": ("HIP events around the K steps of the timed region" if not backward else "separate loop of forward launches (the step holds backward kernels too)"),
+                "frac_from_ms_per_step": fwd_flops(b, s, s, h, d, causal) / (ms_per_step * 1e-3) / 1e12 / PEAK_DENSE_FP16_TFLOPS if not backward else None,
+                "sustained": sustained, "launch_ms_distribution": k_dist,
                 "tflops_at_median_launch": fwd_flops(b, s, s, h, d, causal) / k_dist["median_ms"] / 1e9,
                 "tflops_at_min_launch": fwd_flops(b, s, s, h, d, causal) / k_dist["min_ms"] / 1e9,
                 "power_and_sclk": {"timed_region": power_timed, "sustained": power_sustained},
@@ -707,16 +758,19 @@ def main():
             capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], cz)
             f = ((lambda: capi.mha_bwd(et["q"], et["k"], et["v"], et["o"], et["lse"], et["dout"], et["dq"], et["dk"], et["dv"], et["dsum"], cz)) if bw
                  else (lambda: capi.mha_fwd(et["q"], et["k"], et["v"], et["o"], et["lse"], cz)))
-            t = {capi.POLICY_MFMA32: [], capi.POLICY_MFMA16: []}
-            for _ in range(5):
-                for pol in t:
-                    capi.set_kernel_policy(pol)
-                    f(); sync()
-                    t[pol].append(event_time_ms(torch, f, 3))
-            capi.set_kernel_policy(capi.POLICY_AUTO)
-            m32, m16 = _st.median(t[capi.POLICY_MFMA32]), _st.median(t[capi.POLICY_MFMA16])
+            times = {capi.POLICY_MFMA32: [], capi.POLICY_MFMA16: [], capi.POLICY_AUTO: []}
+            try:
+                for _ in range(5):
+                    for pol in times:
+                        capi.set_kernel_policy(pol)
+                        f(); sync()
+                        times[pol].append(event_time_ms(torch, f, 3))
+            finally:
+                capi.set_kernel_policy(capi.POLICY_AUTO)
+            m32, m16, mauto = (_st.median(times[pol]) for pol in (capi.POLICY_MFMA32, capi.POLICY_MFMA16, capi.POLICY_AUTO))
             stages = ("dq", "dkdv") if bw else ("fwd",)
-            ab[label] = {"ms_mfma_32x32x16": m32, "ms_mfma_16x16x32": m16, "ratio_16_over_32": m16 / m32,
+            ab[label] = {"ms_mfma_32x32x16": m32, "ms_mfma_16x16x32": m16, "ms_auto": mauto, "ratio_16_over_32": m16 / m32,
+                         "ratio_auto_over_best_pinned": mauto / min(m32, m16),
                          "auto_picks": {st_: capi.kernel_name(st_, bb, ss, ss, hh, 128, cz) for st_ in stages}}
             del et
             torch.cuda.empty_cache()

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kDqBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (!decode_work<kDqBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;
     const int head_k = head / p.h_ratio;
 
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     const int kb = wave & 3, qh = wave >> 2;             // key block / q-half of this wave
 
     int tile, batch, vhead, tiles_seq;      // tile = 128-key block of this sequence (compact varlen grid: looked up in cu_seqlens_k)
-    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq)) return;
+    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq, p.tile_major != 0)) return;
     // Few KV heads (GQA / MQA): the grid b * h_k * ceil(sk / 128) is small and, under a causal mask, unbalanced (the first key block
     // of a sequence sees every query tile, the last one a single tile).  With workspace from the caller the group's h / h_k query
     // heads are dealt to n_split workgroups; each leaves fp32 partial sums and fa_bwd_sum_splits_kernel adds them in a fixed order.
@@ -786,11 +786,14 @@ hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t s) {
 constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 20;       // seqlen_q * seqlen_k per head: 1024 x 1024, causal or not, since its ring addressing
                                                               // costs one XOR per base register and tile (profiles/r3_policy_sweep.log, second table:
                                                               // -2..-8 % from 1k on, +-1.5 % at 512); per head, not per launch: fa_fwd_pp.hip says why
+constexpr int64_t kDqMfma16MinPairsCausal = (int64_t)1 << 28;
 static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
     const int policy = kernel_policy();
     if (kp.d != 128 || policy == 0) return false;
     if (policy == 1) return true;
-    if (!dkdv) return !kp.is_causal;
+    // dQ: without a mask always; under a causal mask from 16k x 16k, where every box measured so far has it ahead (ratio 16 / 32 at 16k:
+    // 0.99, 0.97, 0.94, 0.97; at 8k 0.98 .. 1.03: profiles/r3_policy_sweep.log, r4_policy_sweep_after_rowsum.log)
+    if (!dkdv) return !kp.is_causal || (int64_t)kp.seqlen_q * kp.seqlen_k >= kDqMfma16MinPairsCausal;
     return (int64_t)kp.seqlen_q * kp.seqlen_k >= kKvMfma16MinPairs;
 }
 const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv) {
@@ -800,6 +803,7 @@ hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
+    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles);
     if (bwd_use_mfma16(kp, false)) return launch_bwd_dq16(kp, dtype, s);
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
@@ -845,6 +849,8 @@ hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.varlen_slots = kp.cu_seqlens_k != nullptr ? varlen_slot_count(kp.total_k, kp.b, kKvBlockN, kp.n_k_tiles) : 0u;
     kp.n_split = kp.ws != nullptr ? dkdv_split(kp, kp.ws_bytes) : 1;
     kp.ws_rows = dkdv_rows(kp);
+    // (key block 0 is the heaviest under a causal mask: ascending tile order is heaviest first already)
+    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h_k * kp.n_split, kp.seqlen_k, kp.n_k_tiles);
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     const int perm_n = 4 * ((0x3120 >> (4 * (n16 >> 2))) & 3) + (n16 & 3);      // kPerm[n16]: row of a 16-row block that fragment row / column n16 stands for
 
     int tile, batch, vhead, tiles_seq;
-    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq)) return;
+    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq, p.tile_major != 0)) return;
     const int head_k = vhead / p.n_split, split = vhead - head_k * p.n_split;
     const int heads_here = p.h_ratio / p.n_split;            // query heads of this workgroup
 

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     // ---- items of this workgroup ------------------------------------------------------------------------
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;            // heaviest (latest) query tiles first
 
     // ---- geometry (wave-uniform) -----------------------------------------------------------------------
@@ -546,8 +546,11 @@ int set_kernel_policy(int policy) {
     return g_fwd_policy.exchange(policy, std::memory_order_relaxed);
 }
 constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 22;             // 2048 x 2048
-constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 26;       // 8192 x 8192: under a causal mask the late waves of a workgroup idle while the early
-                                                                     // ones finish, the cap binds less, and the break-even moves up
+// Under a causal mask the late waves of a workgroup idle while the early ones finish, the cap binds less and the break-even sits higher.
+// Round 4: with the row sums in the matrix pipe (fp16) the 16x16x32 kernel is ahead from 4k x 4k on (ratio 16 / 32: 0.96 at 4k, 0.94 at 8k,
+// 0.92 at 16k; round 3 without it, three other boxes: 0.98..1.03 / 1.00..1.02 / 1.00), so the threshold came down from 8k x 8k
+// (profiles/r4_policy_sweep_after_rowsum.log next to profiles/r3_policy_sweep.log; bf16 keeps its VALU row sums and sits within +-2.5 % there).
+constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 24;       // 4096 x 4096
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
 
 static bool use_mfma16(const FwdKernelParams& kp) {
@@ -564,10 +567,19 @@ const char* fwd_kernel_name(int d) { return d == 128 && g_fwd_policy.load(std::m
 
 const char* fwd_kernel_name_for(const FwdKernelParams& kp) { return use_mfma16(kp) ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
 
+// fa_fwd_w4.hip: head_dim 128 with one wave per SIMD (development switch while the kernel is being measured)
+#ifndef FA_FWD_W4
+#define FA_FWD_W4 0
+#endif
+bool fwd_w4_eligible(const FwdKernelParams& kp);
+hipError_t launch_fwd_w4(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);
+
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
+    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles);
+    if (FA_FWD_W4 && fwd_w4_eligible(kp)) return launch_fwd_w4(kp, dtype, grid, stream);
     if (use_mfma16(kp)) return launch_fwd_pp16(kp, dtype, grid, stream);
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, grid, stream) : launch_pp_t<_Float16, 64>(kp, grid, stream);
     return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, grid, stream) : launch_pp_t<__bf16, 64>(kp, grid, stream);

@@ -35,8 +35,16 @@ constexpr float kPpDeferLog2 = 6.0f;
 // l is then the sum of the ROUNDED P values (fp32 accumulation in the matrix pipe): O = sum(round(P) V) / sum(round(P)) is a proper convex
 // combination, and LSE carries the rounding noise of P: |dLSE| <= 2^-12 worst case (fp16), ~1.4e-4 / sqrt(effective keys) typical.
 //   0 = off (VALU sums), 1 = fp16 only (default: bf16's 2^-9 would show in LSE on rows dominated by one key), 2 = both dtypes.
+// FA_PP16_EXACT_TILES: the first tiles of every workgroup (and every masked / leftover tile) keep the exact VALU sums of the unrounded P.
+// The rounding noise of a sum of N rounded terms is ~1.4e-4 * sqrt(e / N) of l for N(0,1) scores (2.9e-5 at N = 64, 7e-6 at N = 1024), so
+// rows that see few keys - the first rows of a causal problem, short sequences - would carry 1e-4 in LSE; with 16 exact tiles (1024 keys) a
+// row's MFMA-summed part always rides on >= 1024 exactly summed keys in front of it and the worst LSE deviation measured at the BASELINE
+// sizes stays below 5e-5 (profiles/r4_lse_error_distribution.json).  Costs nothing where it matters: tiles 0..15 of 256 at 16k.
 #ifndef FA_PP16_MFMA_ROWSUM
 #define FA_PP16_MFMA_ROWSUM 1
+#endif
+#ifndef FA_PP16_EXACT_TILES
+#define FA_PP16_EXACT_TILES 16
 #endif
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     // ---- items of this workgroup ------------------------------------------------------------------------
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq)) return;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;            // heaviest (latest) query tiles first
 
     // ---- geometry (wave-uniform) -----------------------------------------------------------------------
@@ -207,15 +215,22 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         const int i = j - NPV, ks = i / NKB, kb = i % NKB;
         return lds_read16((const FA_LDS char*)(uintptr_t)k_rd[ks], slot_k * TILEB + 16 * kb * ROWB);
     };
-    auto m_mfma = [&](auto jc, const u32x4& fr) __attribute__((always_inline)) {
+    // `lsc`: the pending P tile was produced by the MFMA-sum path -> its row sums are taken here (compile-time yes / no, or a run-time bool)
+    bool prev_ml = false;
+    auto m_mfma = [&](auto jc, const u32x4& fr, auto lsc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         if constexpr (j < NPV) {
             constexpr int db = j % DB, cch = j / DB;
             LP<T>::mfma16_acc(oacc[db][0], fr, pf[cch][0]);          // (this accumulator's previous MFMA is DB fragments = 2 * DB MFMAs back)
             LP<T>::mfma16_acc(oacc[db][1], fr, pf[cch][1]);
             if constexpr (ML && db == DB - 1) {                      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
-                LP<T>::mfma16_acc(lacc[0], ones_a, pf[cch][0]);
-                LP<T>::mfma16_acc(lacc[1], ones_a, pf[cch][1]);
+                bool take;
+                if constexpr (std::is_same<decltype(lsc), bool>::value) take = lsc;
+                else take = decltype(lsc)::value;
+                if (take) {
+                    LP<T>::mfma16_acc(lacc[0], ones_a, pf[cch][0]);
+                    LP<T>::mfma16_acc(lacc[1], ones_a, pf[cch][1]);
+                }
             }
         } else {
             constexpr int i = j - NPV, ks = i / NKB, kb = i % NKB;
@@ -230,14 +245,14 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     };
     u32x4 pre[PF];
     // full phase (P.V of the previous tile + QK^T of this one), ring slots as given (compile-time constants in the unrolled loop)
-    auto m_phase = [&](int slot_v, int slot_k) __attribute__((always_inline)) {
+    auto m_phase = [&](int slot_v, int slot_k, auto lsc) __attribute__((always_inline)) {
         u32x4 fr[NST];
         static_for<0, PF>([&](auto jc) { fr[decltype(jc)::value] = pre[decltype(jc)::value]; });
         static_for<0, NST>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (j + PF < NST) fr[j + PF] = m_frag(j + PF, slot_v, slot_k);
             __builtin_amdgcn_sched_barrier(0);
-            m_mfma(jc, fr[j]);
+            m_mfma(jc, fr[j], lsc);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -247,10 +262,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     };
     // un-pipelined halves for the first / diagonal / last tiles
     auto pv_step = [&]() __attribute__((always_inline)) {
-        static_for<0, NPV>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u)); });
+        static_for<0, NPV>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), prev_ml); });
     };
     auto qk_step = [&]() __attribute__((always_inline)) {
-        static_for<NPV, NST>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u)); });
+        static_for<NPV, NST>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), false); });
     };
     auto issue_dma_k = [&](int u) __attribute__((always_inline)) {
         if (u + 2 < n_tiles) dma_k_tile(k_srd, u + 2, ring_um1);
@@ -271,7 +286,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         x = __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
         return sum_both_halves(x);
     };
-    auto softmax_step = [&](int u, auto masked, auto maybe_first) __attribute__((always_inline)) {
+    // `mlc`: this tile's row sums go through the matrix pipe (no VALU adds, packed-max guard) / stay exact in the VALU
+    auto softmax_step = [&](int u, auto masked, auto maybe_first, auto mlc) __attribute__((always_inline)) {
+        constexpr bool MLT = ML && decltype(mlc)::value;
         // the scores were written by MFMAs issued from inline asm, which the hazard recogniser does not see: a 4-pass XDL write needs its
         // wait states before a VALU reads it (the barrier and the DMA issue in between usually cover them; this makes it unconditional)
         asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
@@ -320,12 +337,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 for (int kb = 0; kb < NKB; ++kb) {
                     const float p0 = fast_exp2(__builtin_fmaf(sacc[kb][qb][0], c, -mc0)), p1 = fast_exp2(__builtin_fmaf(sacc[kb][qb][1], c, -mc0));
                     const float p2 = fast_exp2(__builtin_fmaf(sacc[kb][qb][2], c, -mc0)), p3 = fast_exp2(__builtin_fmaf(sacc[kb][qb][3], c, -mc0));
-                    if constexpr (!ML) { ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3; }
+                    if constexpr (!MLT) { ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3; }
                     if (kb & 1) { pf[kb >> 1][qb].z = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].w = LP<T>::pack2(p2, p3); }
                     else { pf[kb >> 1][qb].x = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].y = LP<T>::pack2(p2, p3); }
                 }
             }
-            if constexpr (ML) {
+            if constexpr (MLT) {
                 // largest packed P of the lane, both query columns: positive fp16 / bf16 bit patterns order like unsigned integers, and
                 // v_pk_maximum3_f16 (IEEE maximum: NaN wins) on bf16 bits is monotone as long as they read as finite fp16, i.e. below 2^121;
                 // anything above, Inf and NaN come out as a pattern above kBits64 as well.
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 return !(ps[0] <= 64.0f && ps[1] <= 64.0f);
             }
         };
-        if constexpr (ML) {
+        if constexpr (MLT) {
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(pass()) != 0, 0)) {
                 float mx[2];
 #pragma unroll
@@ -361,6 +378,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                         const float m_new = fmaxf(m_run[qb], mx[qb]);
                         const float alpha = fast_exp2((m_run[qb] - m_new) * c);
                         m_run[qb] = m_new;
+                        l_run[qb] *= alpha;                       // (the exactly summed tiles of this workgroup)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
 #pragma unroll
@@ -394,6 +412,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 const float alpha = fast_exp2((m_run[qb] - m_new) * c);
                 m_run[qb] = m_new;
                 l_run[qb] *= alpha;
+                if constexpr (ML) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
+                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if constexpr (ML) asm volatile("" : "+v"(lacc[qb]));
-            const float l_tot = ML ? lacc[qb][0] : sum4(l_run[qb]);
+            const float l_tot = ML ? sum4(l_run[qb]) + lacc[qb][0] : sum4(l_run[qb]);      // exactly summed tiles + MFMA-summed tiles
             // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
             const float inv = l_tot != 0.f ? fast_rcp(l_tot) : 0.f;
             const float lse = l_tot != 0.f ? (m_run[qb] * c + fast_log2(l_tot)) * kLn2 : 0.f;
@@ -455,8 +477,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         issue_dma_k(u);
         __syncthreads();
         issue_dma_v(u);
-        if (active) softmax_step(u, masked, yes{});
+        if (active) softmax_step(u, masked, yes{}, no{});      // exact row sums in every masked / first tile
         prev_active = active;
+        prev_ml = false;
         end_s_phase();
         advance_ring();
     };
@@ -465,13 +488,14 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     if (n_main > 0) {
         iteration(0, no{});
         if (n_main > 1) m_prefetch(ring_um1, ring_u);
-        auto step_c = [&](int uu, auto um1, auto u0, auto up1) __attribute__((always_inline)) {
+        // lsc: the pending P (tile uu - 1) has its row sums taken by MFMA in this step's matrix phase; mlc: tile uu's softmax leaves them to the next one
+        auto step_c = [&](int uu, auto um1, auto u0, auto up1, auto lsc, auto mlc) __attribute__((always_inline)) {
             constexpr int S_UM1 = decltype(um1)::value, S_U = decltype(u0)::value, S_UP1 = decltype(up1)::value;
-            m_phase(S_UM1, S_U);
+            m_phase(S_UM1, S_U, lsc);
             __syncthreads();
             if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
             if (uu + 1 < n_tiles) dma_v_tile(v_srd, uu + 1, S_UP1);
-            softmax_step(uu, no{}, no{});
+            softmax_step(uu, no{}, no{}, mlc);
             m_prefetch(S_U, S_UP1);
             end_s_phase();
         };
@@ -479,17 +503,40 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         using i1 = std::integral_constant<int, 1>;
         using i2 = std::integral_constant<int, 2>;
         u = 1;
-        for (; u + 3 <= n_main; u += 3) {         // ring slot of tile u is u % 3: three steps per trip make every slot a constant
-            step_c(u, i0{}, i1{}, i2{});
-            step_c(u + 1, i1{}, i2{}, i0{});
-            step_c(u + 2, i2{}, i0{}, i1{});
+        // ring slot of tile u is u % 3: three steps per trip make every slot a constant
+        constexpr int kExact = ML ? 1 + 3 * ((FA_PP16_EXACT_TILES + 1) / 3) : 0;      // first MFMA-summed tile: start of a trip (16 for the default)
+        if constexpr (ML) {
+            for (; u + 3 <= n_main && u + 3 <= kExact; u += 3) {      // exactly summed tiles
+                step_c(u, i0{}, i1{}, i2{}, no{}, no{});
+                step_c(u + 1, i1{}, i2{}, i0{}, no{}, no{});
+                step_c(u + 2, i2{}, i0{}, i1{}, no{}, no{});
+            }
+            if (u == kExact && u + 3 <= n_main) {
+                step_c(u, i0{}, i1{}, i2{}, no{}, yes{});             // the pending P is still an exactly summed one
+                step_c(u + 1, i1{}, i2{}, i0{}, yes{}, yes{});
+                step_c(u + 2, i2{}, i0{}, i1{}, yes{}, yes{});
+                u += 3;
+                for (; u + 3 <= n_main; u += 3) {
+                    step_c(u, i0{}, i1{}, i2{}, yes{}, yes{});
+                    step_c(u + 1, i1{}, i2{}, i0{}, yes{}, yes{});
+                    step_c(u + 2, i2{}, i0{}, i1{}, yes{}, yes{});
+                }
+                prev_ml = true;
+            }
+        } else {
+            for (; u + 3 <= n_main; u += 3) {
+                step_c(u, i0{}, i1{}, i2{}, no{}, no{});
+                step_c(u + 1, i1{}, i2{}, i0{}, no{}, no{});
+                step_c(u + 2, i2{}, i0{}, i1{}, no{}, no{});
+            }
         }
         for (; u < n_main; ++u) {                 // the last one or two steady-state tiles
-            m_phase(ring_um1, ring_u);
+            m_phase(ring_um1, ring_u, prev_ml);
             __syncthreads();
             issue_dma_k(u);
             issue_dma_v(u);
-            softmax_step(u, no{}, no{});
+            softmax_step(u, no{}, no{}, no{});
+            prev_ml = false;
             m_prefetch(ring_u, ring_up1);
             end_s_phase();
             advance_ring();

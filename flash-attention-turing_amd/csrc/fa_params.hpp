@@ -26,6 +26,7 @@ struct FwdKernelParams {
     int32_t is_causal;
     uint32_t n_q_tiles;         // filled by the launcher
     uint32_t varlen_slots;      // filled by the launcher: != 0 -> compact varlen grid (fa_device.hpp), 0 -> plain grid
+    uint32_t tile_major;        // filled by the launcher: plain grid walked tile index first (fa_device.hpp:decode_block)
     int64_t total_q;            // packed token count of q (0 = unknown)
     float scale_log2e;          // log2(e) / sqrt(d)
     float scale;                // 1 / sqrt(d)
@@ -50,6 +51,7 @@ struct BwdKernelParams {
     int32_t is_causal;
     uint32_t n_q_tiles, n_k_tiles;
     uint32_t varlen_slots;      // per launch, like FwdKernelParams
+    uint32_t tile_major;        // per launch, like FwdKernelParams
     int64_t total_q, total_k;   // packed token counts (0 = unknown)
     float scale_log2e;
     float scale;
@@ -60,6 +62,15 @@ struct BwdKernelParams {
     int64_t ws_rows;            // key rows of the whole batch: b * seqlen_k, or total_k for packed tensors
     int32_t n_split;
 };
+
+// Plain causal grids of at most this many 256-row tiles per sequence (<= 4k rows) are walked tile index first (fa_device.hpp:decode_block):
+// longest-processing-time order while a compute unit sees only a few workgroups.  0 = never (A/B switch).
+#ifndef FA_TILE_MAJOR_MAX_ROWS
+#define FA_TILE_MAJOR_MAX_ROWS 4096
+#endif
+inline uint32_t tile_major_for(bool causal, bool compact_grid, int64_t n_bh, int64_t rows, int64_t tiles) {
+    return (FA_TILE_MAJOR_MAX_ROWS > 0 && causal && !compact_grid && (n_bh & 7) == 0 && tiles >= 2 && rows <= FA_TILE_MAJOR_MAX_ROWS) ? 1u : 0u;
+}
 
 // query-head group split chosen for a dK/dV launch (1 = none) and the workspace it needs
 int32_t dkdv_split(const BwdKernelParams& kp, int64_t avail_bytes);

@@ -202,13 +202,13 @@ double fa_fwd_flops(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, in
 double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d);
 /* Name of the forward kernel the library dispatches LARGE problems of this head_dim to (what a profiler's kernel trace of the
  * BASELINE configurations will show; lets a benchmark tie a committed PMC profile to the kernel that actually ran).  head_dim 128
- * has two kernels: problems of seqlen_q * seqlen_k < 2^22 (2^26 under a causal mask) run fa_fwd_pp_kernel, larger ones
+ * has two kernels: problems of seqlen_q * seqlen_k < 2^22 (2^24 under a causal mask) run fa_fwd_pp_kernel, larger ones
  * fa_fwd_pp16_kernel. */
 const char* fa_fwd_kernel_name(int32_t d);
 /* head_dim 128 has two sets of kernels, tiled for v_mfma_f32_32x32x16 and for v_mfma_f32_16x16x32.  Both meet the same tolerances;
  * they differ in speed only: the 16x16x32 shape draws less power per FLOP and wins where the chip's power cap binds (long launches),
  * the 32x32x16 forward needs fewer cycles and wins short ones.  FA_POLICY_AUTO (the default): forward and dK/dV by seqlen_q * seqlen_k (forward as
- * described above, dK/dV from 2^20), dQ 16x16x32 unless the mask is causal - never by batch or head count, so a
+ * described above, dK/dV from 2^20), dQ 16x16x32 unless the mask is causal (then from 2^28) - per head, never by batch or head count, so a
  * (batch, head) shard of a problem gets the bits the whole problem gets; FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
  * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 is not affected.  The reference has no counterpart. */
 #define FA_POLICY_MFMA32 0

@@ -17,12 +17,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, extra=()):
+def _launch(world, extra=(), env_extra=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5",
                                        "--warmup", "1", "--fake-step", *extra], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
@@ -90,6 +90,22 @@ def test_nccl_unavailable_falls_back_to_gloo():
     assert r["n_gpus"] == 2 and r["units_total"] == 2 * 4 * 32 and r["ms_per_step"] >= 4.0
 
 
+def test_subgroup_adoption_success_branch_with_a_stand_in_backend():
+    """The branch a real 8-GPU run takes and no 1-GPU box can: every rank reports its "nccl" subgroup initialised -> the gloo MIN agrees
+    -> the subgroup is ADOPTED and the timed region's barriers and the MAX / SUM reductions go through it.  A gloo subgroup stands in
+    for RCCL (FA_BENCH_SUBGROUP_BACKEND=gloo); the bookkeeping of the run must be what the plain gloo run gives."""
+    for world in (2, 4):
+        outs = _launch(world, extra=("--backend", "nccl"), env_extra={"FA_BENCH_SUBGROUP_BACKEND": "gloo"})
+        r = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+        assert r["comm_backend"].startswith("gloo subgroup standing in for nccl"), r["comm_backend"]
+        # timed_region: 2 barriers; headline MAX + units SUM; the strong sweep adds its own -> the adopted group carried them all
+        assert r["subgroup_collectives"]["barrier"] >= 2 and r["subgroup_collectives"]["all_reduce"] >= 2, r["subgroup_collectives"]
+        assert r["n_gpus"] == world and r["units_total"] == world * 4 * 32
+        assert r["ms_per_step"] >= 2.0 * world                       # MAX over ranks went through the subgroup: the slowest rank's time
+        for pt in r["extra"]["sweep_strong"].values():
+            assert pt["units_total"] == 4 * 32, pt
+
+
 def test_gloo_backend_is_reported():
     r = json.loads([l for l in _launch(2, extra=("--backend", "gloo"))[0][0].splitlines() if l.startswith("{")][0])
     assert r["comm_backend"] == "gloo"
@@ -118,14 +134,25 @@ def test_gpus_flag_needs_that_many_devices():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "ROCm" in (out.stderr + out.stdout)
-    sys.path.insert(0, ROOT)
-    import inspect
 
-    import bench
 
-    src = inspect.getsource(bench.main)
-    assert src.index("device_count()") < src.index("make_inputs("), "the device-count check must precede the first allocation"
-    assert "one rank per GPU is required" in src
+def test_gpus_flag_with_too_few_devices_stops_before_any_allocation():
+    """behavioural form of the above for N > 1: two ranks, a torch that claims ONE visible device (patched in the child processes; there
+    is no GPU here, so any allocation or kernel launch would die with a different error first): both ranks must stop with the
+    device-count message"""
+    port = _free_port()
+    prog = ("import sys, runpy, torch;"
+            "torch.cuda.is_available = lambda: True; torch.cuda.device_count = lambda: 1;"
+            f"sys.argv = [{os.path.join(ROOT, 'bench.py')!r}, '--gpus', '2', '--steps', '1', '--backend', 'gloo'];"
+            f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode != 0, (o, e)
+        assert "only 1 ROCm device(s) visible" in (o + e) and "one rank per GPU is required" in (o + e), (o + e)[-1500:]
 
 
 def test_clockbench_parser_reads_the_current_table_and_reports_drift():

@@ -4,7 +4,8 @@ Under the default policy the forward and dK/dV pick by seqlen_q * seqlen_k and d
 fa_set_kernel_policy), so the rest of the suite reaches fa_fwd_pp16.hip / fa_bwd_dkdv16.hip only in the full-size tests and the 32x32x16
 dQ at head_dim 128 only under a causal mask.  Every test below runs twice: pinned to the 16x16x32 set and pinned to the 32x32x16 set.
 
-The launcher gives it the LARGE launches only (>= 2^29 (query, key) pairs, 2^31 under a causal mask: include/flash_attn_gfx950.h, fa_set_kernel_policy), so
+The launcher gives the 16x16x32 forward the large problems only (seqlen_q * seqlen_k >= 2^22 per head, 2^24 under a causal mask; dK/dV from 2^20; dQ without
+a mask, under one from 2^28: include/flash_attn_gfx950.h, fa_set_kernel_policy), so
 of the suite only the full-size value-parity and property tests reach it on their own.  This module pins the policy to that kernel
 and runs the forward-facing tests of the other modules again at head_dim 128: the golden vectors, the C-oracle cases, the
 reference's (sq, sk) grid, packed sequences, the softmax edge cases - every tail, mask and head-group path of the kernel.  It also

@@ -15,7 +15,8 @@ print(row("C5 shard fwd b4 s16k non-causal", e["c5shard"]["fwd_ms"], e["c5shard"
 print(row("C4 fwd (bf16 s8k)", c4["fwd_ms"], c4["fwd_tflops"]))
 print(row("C4 bwd (dQ incl. D + dK/dV)", c4["bwd_ms"], c4["bwd_tflops"]))
 print(row("C4 fwd+bwd", c4["fwd_ms"] + c4["bwd_ms"], c4["fwd_bwd_tflops"]))
-print(f"CPU oracle: {d['cpu_baseline']['value']:.3f} TFLOP/s on {d['cpu_baseline']['cores']} threads")
+cb = d['cpu_baseline']
+print(f"CPU baseline ({cb.get('kind')}): {cb['value']:.3f} TFLOP/s on {cb['cores']} threads" + (f"; C-oracle port {cb['oracle_port']['value']:.3f} TFLOP/s on {cb['oracle_port']['cores']} threads" if 'oracle_port' in cb else ""))
 print("backward kernels alone:", {k: (round(v["avg_launch_ms"], 3), round(v["achieved"])) for k, v in rb.items()})
 g = e["gqa_bwd_b4_s8192_d128_bf16_causal"]
 print("GQA/MQA causal bwd ms:", {k: (round(v["bwd_ms"], 2), round(v["bwd_ms_without_workspace"], 2), round(v["vs_mha"], 2)) for k, v in g.items()})
