@@ -32,11 +32,10 @@ LIB_NAME = "libflash_attn_gfx950.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 EXT_PATH = os.path.join(PKG, "_C.so")
 
-HIP_SOURCES = ["fa_fwd_pp.hip", "fa_fwd_pp16.hip", "fa_fwd_w4.hip", "fa_bwd.hip", "fa_bwd_dq16.hip", "fa_bwd_dkdv16.hip", "fa_capi.hip"]
+HIP_SOURCES = ["fa_fwd_pp.hip", "fa_fwd_pp16.hip", "fa_bwd.hip", "fa_bwd_dq16.hip", "fa_bwd_dkdv16.hip", "fa_capi.hip"]
 # per-file extra flags.  fa_fwd_pp16.hip: hipcc's SLP vectoriser packs the softmax row-sum adds and the O rescale into v_pk_* on register
 # pairs it first has to assemble from the 4-register MFMA tiles: ~200 v_mov_b64 per three tiles and 44-116 bytes of spills on the hot path
-# fa_fwd_w4.hip owns the accumulation registers from inline asm: hipcc must not park spilled VGPRs there
-EXTRA_FLAGS = {"fa_fwd_pp16.hip": ["-fno-slp-vectorize"], "fa_fwd_w4.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"], "fa_bwd_dq16.hip": ["-fno-slp-vectorize"], "fa_bwd_dkdv16.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"fa_fwd_pp16.hip": ["-fno-slp-vectorize"], "fa_bwd_dq16.hip": ["-fno-slp-vectorize"], "fa_bwd_dkdv16.hip": ["-fno-slp-vectorize"]}
 HIP_HEADERS = ["fa_device.hpp", "fa_params.hpp", "fa_bwd_dkdv_common.hpp", os.path.join(INCLUDE, "flash_attn_gfx950.h")]
 # -amdgpu-mfma-vgpr-form: builtin MFMAs keep their result in VGPRs even in kernels that may use the
 # accumulator half of the register file (the dK/dV kernel parks its 128 long-lived accumulator

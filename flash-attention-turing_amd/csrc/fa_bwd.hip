@@ -26,6 +26,7 @@
 //     dK/dV and reduces with torch::sum_out, flash_api.cpp:265-272,301-312); with caller-provided fp32 scratch the group is
 //     split over workgroups when the grid would otherwise be small or causally unbalanced;
 //   * operands that never change inside a kernel's loop live in registers (Q / dO fragments in dQ, K and part of V in dK/dV).
+#include <atomic>
 #include <type_traits>
 #include "fa_bwd_dkdv_common.hpp"
 
@@ -576,6 +577,8 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #ifdef FA_KV_TIMING
     uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
+    // (a static s_setprio 1 for the younger q-half, which buys the 16x16x32 dK/dV kernel 1-3 %, measures +-0.2 % here and in both dQ kernels:
+    // profiles/r4_bwd_prio_dq_dkdv32_ab.log)
     int cur_tile = 0;                                       // tile-in-head index of the tile being computed
     for (int it = 0; it < n_iters; ++it) {
         const int m0 = (qt_begin + cur_tile) * kKvBlockM;
@@ -817,17 +820,27 @@ static int64_t dkdv_rows(const BwdKernelParams& kp) { return kp.cu_seqlens_k != 
 int64_t dkdv_workspace_bytes(const BwdKernelParams& kp, int32_t n_split) {
     return n_split <= 1 ? 0 : 2 * (int64_t)n_split * dkdv_rows(kp) * kp.h_k * kp.d * 4;
 }
-// CUs of the current device (the split target is "workgroups per CU"); 256 = MI355X when there is no device (host-only callers).
+// CUs of the CURRENT device (the split target is "workgroups per CU"), cached per device id (a process may drive devices or partitions with
+// different CU counts: ADVICE r3); 256 = MI355X when there is no usable device (host-only callers such as fa_bwd_workspace_bytes on a build box).
+// Consequence, stated in the public header: the summation order of GQA / MQA dK / dV with a workspace depends on the device's CU count.
 static int64_t device_cu_count() {
-    static const int64_t cached = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-            (void)hipGetLastError();                     // a box without a GPU: do not leave a sticky error behind
-            return (int64_t)256;
-        }
-        return (int64_t)n;
-    }();
-    return cached;
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+        (void)hipGetLastError();                         // a box without a GPU: do not leave a sticky error behind
+        return 256;
+    }
+    if (dev < 64) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 int32_t dkdv_split(const BwdKernelParams& kp, int64_t avail_bytes) {
     if (kp.h_ratio <= 1 || dkdv_rows(kp) <= 0) return 1;
@@ -850,7 +863,7 @@ hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_split = kp.ws != nullptr ? dkdv_split(kp, kp.ws_bytes) : 1;
     kp.ws_rows = dkdv_rows(kp);
     // (key block 0 is the heaviest under a causal mask: ascending tile order is heaviest first already)
-    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h_k * kp.n_split, kp.seqlen_k, kp.n_k_tiles);
+    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h_k * kp.n_split, kp.seqlen_k, kp.n_k_tiles, FA_TILE_MAJOR_MAX_ROWS_DKDV);
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     constexpr int TILEB = kKvBlockM * ROWB;                 // one Q (or dO) tile
     constexpr int STATB = 2 * kKvBlockM * 4;                // lse2 + dsum of one tile
     constexpr int OFF_V = KVB, OFF_Q = 2 * KVB, OFF_DO = 2 * KVB + 2 * TILEB, OFF_STAT = 2 * KVB + 4 * TILEB;
-    __shared__ __attribute__((aligned(16))) char smem_raw[OFF_STAT + 2 * STATB];
+    // aligned to the toggle span: the ring-slot toggle XORs ABSOLUTE LDS addresses with TILEB / STATB, which is only a slot switch when the
+    // array starts at a multiple of 2 * TILEB (it is the kernel's only __shared__ object and sat at 0 anyway)
+    __shared__ __attribute__((aligned(32768))) char smem_raw[OFF_STAT + 2 * STATB];
     FA_LDS char* smem = (FA_LDS char*)smem_raw;
     FA_LDS char* ktile = smem;
     FA_LDS char* vtile = smem + OFF_V;
@@ -218,8 +220,23 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) vreg[ks][kc] = lds_read16(vtile, row_rd[ks] + (kb * 32 + 16 * kc) * ROWB);
 
+    // FA_KV_PRIO (round 4): issue priority between the two q-half groups, which share every SIMD pairwise.  Waves 0-3 are the older ones,
+    // win every arbitration and wait ~1000 of ~3700 cycles per tile at the barrier.  1 (shipped) = waves 4-7 at priority 1 for
+    // the whole loop: -1.1..-3.4 % on every shape but causal 2k (+0.3 %); 2 = the groups alternate tile by tile: +0..2 %; 3 = waves 0-3 at
+    // priority 1 (control): -1..+1 %.  profiles/r4_bwd_dkdv_prio_ab.log
+#ifndef FA_KV_PRIO
+#define FA_KV_PRIO 1
+#endif
+#if FA_KV_PRIO == 1
+    if (qh == 1) __builtin_amdgcn_s_setprio(1);
+#elif FA_KV_PRIO == 3
+    if (qh == 0) __builtin_amdgcn_s_setprio(1);
+#endif
     int cur_tile = 0;
     for (int it = 0; it < n_iters; ++it) {
+#if FA_KV_PRIO == 2
+        if ((it ^ qh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const int m0 = (qt_begin + cur_tile) * kKvBlockM;
         if (++cur_tile == tiles_per_head) cur_tile = 0;
         const int buf = it & 1;

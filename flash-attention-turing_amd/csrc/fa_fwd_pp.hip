@@ -567,19 +567,14 @@ const char* fwd_kernel_name(int d) { return d == 128 && g_fwd_policy.load(std::m
 
 const char* fwd_kernel_name_for(const FwdKernelParams& kp) { return use_mfma16(kp) ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
 
-// fa_fwd_w4.hip: head_dim 128 with one wave per SIMD (development switch while the kernel is being measured)
-#ifndef FA_FWD_W4
-#define FA_FWD_W4 0
-#endif
-bool fwd_w4_eligible(const FwdKernelParams& kp);
-hipError_t launch_fwd_w4(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);
-
+// (Round 4 built a third head_dim-128 forward, one wave per SIMD with 64 query rows per wave and O / Q in asm-owned accumulation registers,
+// fa_fwd_w4.hip: bit-identical to fa_fwd_pp16 and 7-12 % slower - a lone wave cannot issue 16x16x32 MFMAs at the pipe's rate.  Not in the
+// product; profiles/r4_fwd_w4_one_wave_per_simd_ab.log, file in the history.)
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles);
-    if (FA_FWD_W4 && fwd_w4_eligible(kp)) return launch_fwd_w4(kp, dtype, grid, stream);
     if (use_mfma16(kp)) return launch_fwd_pp16(kp, dtype, grid, stream);
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, grid, stream) : launch_pp_t<_Float16, 64>(kp, grid, stream);
     return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, grid, stream) : launch_pp_t<__bf16, 64>(kp, grid, stream);

@@ -63,13 +63,18 @@ struct BwdKernelParams {
     int32_t n_split;
 };
 
-// Plain causal grids of at most this many 256-row tiles per sequence (<= 4k rows) are walked tile index first (fa_device.hpp:decode_block):
-// longest-processing-time order while a compute unit sees only a few workgroups.  0 = never (A/B switch).
+// Plain causal grids of sequences up to this many rows are walked tile index first (fa_device.hpp:decode_block): longest-processing-time
+// order while a compute unit sees only a few workgroups.  Measured (profiles/r4_causal_tile_order_ab.log, r4_causal_tile_order_long_ab.log):
+// forward / dQ -12..-30 % at 1k-4k, -2..-9 % at 8k, dK/dV -3..-25 % up to 4k but +3.6 % at 8k (head_dim 128); at 16k every kernel loses
+// 6-12 % (a head's K / V no longer stays in its XCD's L2 while its tiles run at different times).  0 = never (A/B switch).
 #ifndef FA_TILE_MAJOR_MAX_ROWS
-#define FA_TILE_MAJOR_MAX_ROWS 4096
+#define FA_TILE_MAJOR_MAX_ROWS 8192
 #endif
-inline uint32_t tile_major_for(bool causal, bool compact_grid, int64_t n_bh, int64_t rows, int64_t tiles) {
-    return (FA_TILE_MAJOR_MAX_ROWS > 0 && causal && !compact_grid && (n_bh & 7) == 0 && tiles >= 2 && rows <= FA_TILE_MAJOR_MAX_ROWS) ? 1u : 0u;
+#ifndef FA_TILE_MAJOR_MAX_ROWS_DKDV
+#define FA_TILE_MAJOR_MAX_ROWS_DKDV (FA_TILE_MAJOR_MAX_ROWS < 4096 ? FA_TILE_MAJOR_MAX_ROWS : 4096)
+#endif
+inline uint32_t tile_major_for(bool causal, bool compact_grid, int64_t n_bh, int64_t rows, int64_t tiles, int64_t max_rows = FA_TILE_MAJOR_MAX_ROWS) {
+    return (max_rows > 0 && causal && !compact_grid && (n_bh & 7) == 0 && tiles >= 2 && rows <= max_rows) ? 1u : 0u;
 }
 
 // query-head group split chosen for a dK/dV launch (1 = none) and the workspace it needs

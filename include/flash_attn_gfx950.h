@@ -209,7 +209,9 @@ const char* fa_fwd_kernel_name(int32_t d);
  * they differ in speed only: the 16x16x32 shape draws less power per FLOP and wins where the chip's power cap binds (long launches),
  * the 32x32x16 forward needs fewer cycles and wins short ones.  FA_POLICY_AUTO (the default): forward and dK/dV by seqlen_q * seqlen_k (forward as
  * described above, dK/dV from 2^20), dQ 16x16x32 unless the mask is causal (then from 2^28) - per head, never by batch or head count, so a
- * (batch, head) shard of a problem gets the bits the whole problem gets; FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
+ * (batch, head) shard of a problem gets the bits the whole problem gets (one exception: dK / dV of a GQA / MQA call that is given a
+ * workspace - how far a head group is split, hence the order its partial sums are added in, follows the launch's workgroup count and the
+ * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit); FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
  * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 is not affected.  The reference has no counterpart. */
 #define FA_POLICY_MFMA32 0
 #define FA_POLICY_MFMA16 1
