@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kDqBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
+    if (!decode_work<kDqBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.group_heads)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;
     const int head_k = head / p.h_ratio;
 
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
     const int kb = wave & 3, qh = wave >> 2;             // key block / q-half of this wave
 
     int tile, batch, vhead, tiles_seq;      // tile = 128-key block of this sequence (compact varlen grid: looked up in cu_seqlens_k)
-    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq, p.tile_major != 0)) return;
+    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq, p.group_heads)) return;
     // Few KV heads (GQA / MQA): the grid b * h_k * ceil(sk / 128) is small and, under a causal mask, unbalanced (the first key block
     // of a sequence sees every query tile, the last one a single tile).  With workspace from the caller the group's h / h_k query
     // heads are dealt to n_split workgroups; each leaves fp32 partial sums and fa_bwd_sum_splits_kernel adds them in a fixed order.
@@ -806,7 +806,7 @@ hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
-    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles);
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles, kp.d == 64 ? 2 : 1);
     if (bwd_use_mfma16(kp, false)) return launch_bwd_dq16(kp, dtype, s);
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
@@ -863,7 +863,7 @@ hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_split = kp.ws != nullptr ? dkdv_split(kp, kp.ws_bytes) : 1;
     kp.ws_rows = dkdv_rows(kp);
     // (key block 0 is the heaviest under a causal mask: ascending tile order is heaviest first already)
-    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h_k * kp.n_split, kp.seqlen_k, kp.n_k_tiles, FA_TILE_MAJOR_MAX_ROWS_DKDV);
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h_k * kp.n_split, kp.seqlen_k, kp.n_k_tiles, kp.d == 64 ? 2 : 1);
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     const int perm_n = 4 * ((0x3120 >> (4 * (n16 >> 2))) & 3) + (n16 & 3);      // kPerm[n16]: row of a 16-row block that fragment row / column n16 stands for
 
     int tile, batch, vhead, tiles_seq;
-    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq, p.tile_major != 0)) return;
+    if (!decode_work<kKvBlockN>(blockIdx.x, p.n_k_tiles, p.varlen_slots, p.cu_seqlens_k, p.b, p.h_k * p.n_split, tile, batch, vhead, tiles_seq, p.group_heads)) return;
     const int head_k = vhead / p.n_split, split = vhead - head_k * p.n_split;
     const int heads_here = p.h_ratio / p.n_split;            // query heads of this workgroup
 
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     // FA_KV_PRIO (round 4): issue priority between the two q-half groups, which share every SIMD pairwise.  Waves 0-3 are the older ones,
     // win every arbitration and wait ~1000 of ~3700 cycles per tile at the barrier.  1 (shipped) = waves 4-7 at priority 1 for
     // the whole loop: -1.1..-3.4 % on every shape but causal 2k (+0.3 %); 2 = the groups alternate tile by tile: +0..2 %; 3 = waves 0-3 at
-    // priority 1 (control): -1..+1 %.  profiles/r4_bwd_dkdv_prio_ab.log
+    // priority 1 (control): -1..+1 %.  profiles/r4_bwd_dkdv_prio_ab.log.  (+1 inside the MFMA clusters, with or without the static offset: +1..6 %,
+    // profiles/r4_prio_mfma_phase_ab.log.)
 #ifndef FA_KV_PRIO
 #define FA_KV_PRIO 1
 #endif

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
     const int pi2_g = (0x3120 >> (4 * g)) & 3;            // key sub-blocks {0, 2, 1, 3}
 
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kDq16BlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
+    if (!decode_work<kDq16BlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.group_heads)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;
     const int head_k = head / p.h_ratio;
 

@@ -329,18 +329,23 @@ FA_DEV u32x4 pack_c_half(const f32x16& c, int half) {
 // (block id % 8); every XCD has a private 4 MiB L2.  All tiles that share one (batch, head)
 // K/V stream are placed on the same XCD so K/V is fetched from HBM once per XCD, not once per
 // workgroup.  Falls back to the plain order when batch*heads is not a multiple of 8.
-// tile_major (round 4): the same XCD rule, but a whole "generation" of equal tile indices is dispatched before the next one.  Under a causal
-// mask the work of a tile grows with its index; heaviest-first WITHIN a head hands every compute unit that finishes a light tile the next
-// head's heavy one and leaves the chip unbalanced while there are only a few workgroups per compute unit (1k .. 4k rows); heaviest-first
-// ACROSS heads is the longest-processing-time order (tools/sched_sim.py, profiles/r4_causal_tile_order_ab.log).  K / V of a head are then
-// streamed at different times by its tiles - from the 256 MiB cache behind the L2s at these sizes.
-FA_DEV void decode_block(uint32_t id, uint32_t tiles_per_bh, uint32_t n_bh, uint32_t& tile, uint32_t& bh, bool tile_major = false) {
+// group_heads (round 4): the same XCD rule, but the (batch, head) streams of an XCD are dispatched in GROUPS of `group_heads`, tile index first
+// within a group.  Under a causal mask the work of a tile grows with its index.  Heaviest-first WITHIN one head (rounds 1-3) is the
+// longest-processing-time order only while a head brings at least two workgroups per compute unit (64 query tiles = 16k rows); with fewer, the unit
+// that finishes a LIGHT tile first is handed the next head's HEAVIEST one and the chip runs unbalanced (at 1k rows 16 + 16 tile-iterations on some
+// units where 20 would do).  Heaviest-first ACROSS all heads balances but lets a head's tiles run at different times, so its K / V is streamed
+// from HBM once per tile generation (measured: wins 12-30 % up to 4k rows, loses 6-12 % at 16k).  Groups of ~2 workgroups per compute unit -
+// group_heads = ceil(2 * workgroup slots of an XCD / tiles per sequence) - give every unit a heavy and a light tile of the same few heads: balance
+// AND locality (tools/sched_sim.py, profiles/r4_causal_tile_order_ab.log, r4_causal_group_order_ab.log).  0 = one head after the other.
+FA_DEV void decode_block(uint32_t id, uint32_t tiles_per_bh, uint32_t n_bh, uint32_t& tile, uint32_t& bh, uint32_t group_heads = 0) {
     if ((n_bh & 7u) == 0) {
         uint32_t xcd = id & 7u, slot = id >> 3;
-        if (tile_major) {
-            const uint32_t per_xcd = n_bh >> 3;
-            tile = slot / per_xcd;
-            bh = (slot % per_xcd) * 8u + xcd;
+        if (group_heads > 1) {
+            const uint32_t per_xcd = n_bh >> 3, span = group_heads * tiles_per_bh;
+            const uint32_t grp = slot / span, within = slot - grp * span;
+            const uint32_t here = min(group_heads, per_xcd - grp * group_heads);      // the last group may hold fewer heads
+            tile = within / here;
+            bh = (grp * group_heads + (within - tile * here)) * 8u + xcd;
             return;
         }
         bh = (slot / tiles_per_bh) * 8u + xcd;
@@ -409,7 +414,7 @@ FA_DEV bool varlen_slot_lookup(const int32_t* cu, int b, uint32_t slot, int& seq
 // `tile` comes back un-reversed; `ntiles` = tiles of THIS sequence (compact) or tiles_per_bh (plain) for the causal reversal.
 template <int BM>
 FA_DEV bool decode_work(uint32_t id, uint32_t tiles_per_bh, uint32_t slots, const int32_t* cu, int b, int nheads,
-                        int& tile, int& batch, int& head, int& ntiles, bool tile_major = false) {
+                        int& tile, int& batch, int& head, int& ntiles, uint32_t group_heads = 0) {
     if (slots != 0) {
         uint32_t slot, hd;
         decode_block(id, slots, (uint32_t)nheads, slot, hd);
@@ -417,7 +422,7 @@ FA_DEV bool decode_work(uint32_t id, uint32_t tiles_per_bh, uint32_t slots, cons
         return varlen_slot_lookup<BM>(cu, b, slot, batch, tile, ntiles);
     }
     uint32_t t, bh;
-    decode_block(id, tiles_per_bh, (uint32_t)(b * nheads), t, bh, tile_major);
+    decode_block(id, tiles_per_bh, (uint32_t)(b * nheads), t, bh, group_heads);
     tile = (int)t; batch = (int)(bh / (uint32_t)nheads); head = (int)(bh % (uint32_t)nheads); ntiles = (int)tiles_per_bh;
     return true;
 }

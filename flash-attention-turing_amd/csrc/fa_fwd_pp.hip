@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     // ---- items of this workgroup ------------------------------------------------------------------------
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.group_heads)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;            // heaviest (latest) query tiles first
 
     // ---- geometry (wave-uniform) -----------------------------------------------------------------------
@@ -574,7 +574,9 @@ hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
-    kp.tile_major = tile_major_for(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles);
+    // (head_dim 64 runs two workgroups per compute unit except in its 128-key causal shape, launch_pp_t)
+    const int wg_per_cu = (kp.d == 64 && !(FA_FWD_D64_BN != 0 ? FA_FWD_D64_BN == 128 : (kp.is_causal && kp.seqlen_k >= kFwdD64WideMinKeys))) ? 2 : 1;
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles, wg_per_cu);
     if (use_mfma16(kp)) return launch_fwd_pp16(kp, dtype, grid, stream);
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, grid, stream) : launch_pp_t<_Float16, 64>(kp, grid, stream);
     return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, grid, stream) : launch_pp_t<__bf16, 64>(kp, grid, stream);

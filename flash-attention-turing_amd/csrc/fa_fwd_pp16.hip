@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     // ---- items of this workgroup ------------------------------------------------------------------------
     int tile, batch, head, tiles_seq;
-    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.tile_major != 0)) return;
+    if (!decode_work<kFwdBlockM>(blockIdx.x, p.n_q_tiles, p.varlen_slots, p.cu_seqlens_q, p.b, p.h, tile, batch, head, tiles_seq, p.group_heads)) return;
     if (CAUSAL) tile = tiles_seq - 1 - tile;            // heaviest (latest) query tiles first
 
     // ---- geometry (wave-uniform) -----------------------------------------------------------------------
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     };
     u32x4 pre[PF];
     // full phase (P.V of the previous tile + QK^T of this one), ring slots as given (compile-time constants in the unrolled loop)
+    // (the matrix phase at issue priority 1, so that the partner's softmax VALU yields to the MFMA stream: +-1 %, profiles/r4_prio_mfma_phase_ab.log)
     auto m_phase = [&](int slot_v, int slot_k, auto lsc) __attribute__((always_inline)) {
         u32x4 fr[NST];
         static_for<0, PF>([&](auto jc) { fr[decltype(jc)::value] = pre[decltype(jc)::value]; });

@@ -26,7 +26,7 @@ struct FwdKernelParams {
     int32_t is_causal;
     uint32_t n_q_tiles;         // filled by the launcher
     uint32_t varlen_slots;      // filled by the launcher: != 0 -> compact varlen grid (fa_device.hpp), 0 -> plain grid
-    uint32_t tile_major;        // filled by the launcher: plain grid walked tile index first (fa_device.hpp:decode_block)
+    uint32_t group_heads;       // filled by the launcher: dispatch order of a plain causal grid (fa_device.hpp:decode_block), 0 = one head after the other
     int64_t total_q;            // packed token count of q (0 = unknown)
     float scale_log2e;          // log2(e) / sqrt(d)
     float scale;                // 1 / sqrt(d)
@@ -51,7 +51,7 @@ struct BwdKernelParams {
     int32_t is_causal;
     uint32_t n_q_tiles, n_k_tiles;
     uint32_t varlen_slots;      // per launch, like FwdKernelParams
-    uint32_t tile_major;        // per launch, like FwdKernelParams
+    uint32_t group_heads;       // per launch, like FwdKernelParams
     int64_t total_q, total_k;   // packed token counts (0 = unknown)
     float scale_log2e;
     float scale;
@@ -63,18 +63,21 @@ struct BwdKernelParams {
     int32_t n_split;
 };
 
-// Plain causal grids of sequences up to this many rows are walked tile index first (fa_device.hpp:decode_block): longest-processing-time
-// order while a compute unit sees only a few workgroups.  Measured (profiles/r4_causal_tile_order_ab.log, r4_causal_tile_order_long_ab.log):
-// forward / dQ -12..-30 % at 1k-4k, -2..-9 % at 8k, dK/dV -3..-25 % up to 4k but +3.6 % at 8k (head_dim 128); at 16k every kernel loses
-// 6-12 % (a head's K / V no longer stays in its XCD's L2 while its tiles run at different times).  0 = never (A/B switch).
-#ifndef FA_TILE_MAJOR_MAX_ROWS
-#define FA_TILE_MAJOR_MAX_ROWS 8192
+// Dispatch order of a plain causal grid (fa_device.hpp:decode_block): how many (batch, head) streams of an XCD are walked together, tile index first.
+// Up to 4096 rows: all of them (longest-processing-time order across heads: -12..-30 % against one head after the other at 1k-4k).  Longer
+// sequences: ~2 workgroups per compute unit at a time, ceil(2 x 32 x wg_per_cu / tiles) heads (2 heads at 8k rows and head_dim 128: -1..2 %; one
+// head from 16k on = the order of rounds 1-3, where a head alone is two workgroups per unit and its K / V stays in the XCD's L2).  `wg_per_cu` =
+// workgroups of this kernel a compute unit holds at a time (2 for the narrow head_dim-64 kernels); an XCD has 32 compute units.
+// FA_CAUSAL_ORDER 0 = one head after the other everywhere (A/B).  profiles/r4_causal_tile_order_ab.log, r4_causal_tile_order_long_ab.log, r4_causal_group_order_ab.log
+#ifndef FA_CAUSAL_ORDER
+#define FA_CAUSAL_ORDER 1
 #endif
-#ifndef FA_TILE_MAJOR_MAX_ROWS_DKDV
-#define FA_TILE_MAJOR_MAX_ROWS_DKDV (FA_TILE_MAJOR_MAX_ROWS < 4096 ? FA_TILE_MAJOR_MAX_ROWS : 4096)
-#endif
-inline uint32_t tile_major_for(bool causal, bool compact_grid, int64_t n_bh, int64_t rows, int64_t tiles, int64_t max_rows = FA_TILE_MAJOR_MAX_ROWS) {
-    return (max_rows > 0 && causal && !compact_grid && (n_bh & 7) == 0 && tiles >= 2 && rows <= max_rows) ? 1u : 0u;
+inline uint32_t causal_group_heads(bool causal, bool compact_grid, int64_t n_bh, int64_t rows, int64_t tiles, int wg_per_cu) {
+    if (FA_CAUSAL_ORDER == 0 || !causal || compact_grid || (n_bh & 7) != 0 || tiles < 2) return 0u;
+    const int64_t per_xcd = n_bh >> 3;
+    if (rows <= 4096) return (uint32_t)per_xcd;
+    const int64_t g = (2 * 32 * (int64_t)wg_per_cu + tiles - 1) / tiles;
+    return g <= 1 ? 0u : (uint32_t)(g < per_xcd ? g : per_xcd);
 }
 
 // query-head group split chosen for a dK/dV launch (1 = none) and the workspace it needs

@@ -222,6 +222,36 @@ def test_d64_forward_tile_shapes(gpu, sq, sk):
         assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
 
 
+@pytest.mark.parametrize("b,h,hk,s,d", [(2, 12, 12, 1280, 128), (1, 8, 8, 2304, 64), (3, 8, 2, 1100, 128), (1, 16, 16, 4200, 128), (2, 5, 5, 1300, 128)])
+def test_causal_grid_walked_tile_index_first(gpu, b, h, hk, s, d):
+    """Round 4: plain causal grids are dispatched in groups of (batch, head) streams, tile index first inside a group, when batch * heads is a
+    multiple of 8 (fa_device.hpp:decode_block, fa_params.hpp:causal_group_heads): all heads of an XCD together up to 4096 rows, ~2 workgroups per
+    compute unit beyond.  The block-id -> (tile, batch, head) map must still hit every item exactly once - a missed item leaves its rows
+    unwritten: the outputs start as NaN here and every tensor is checked against fp32 math.  The 4200-row case is on the grouped side of the
+    4096-row switch (16 query tiles -> groups of 4 heads, only 2 per XCD here: a partial group; its 33 key blocks of dK/dV -> groups of 2);
+    batch x heads = 24, 8, 24, 16 take the new path, 10 (not a multiple of 8) the old one."""
+    import flash_attn_turing as F
+    from flash_attn_turing import capi
+
+    gen = torch.Generator(device="cpu").manual_seed(s + h)
+    q, do = (torch.randn(b, s, h, d, generator=gen).to(gpu, torch.float16) for _ in range(2))
+    k, v = (torch.randn(b, s, hk, d, generator=gen).to(gpu, torch.float16) for _ in range(2))
+    o, dq = (torch.full_like(q, float("nan")) for _ in range(2))
+    dk, dv = (torch.full_like(k, float("nan")) for _ in range(2))
+    lse, dsum = (torch.full((b, h, s), float("nan"), device=gpu, dtype=torch.float32) for _ in range(2))
+    capi.mha_fwd(q, k, v, o, lse, True)
+    capi.mha_bwd(q, k, v, o, lse, do, dq, dk, dv, dsum, True)
+    torch.cuda.synchronize()
+    o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(q, k, v, do, True)
+    for got, ref, name in ((o, o_r, "O"), (dq, dq_r, "dQ"), (dk, dk_r, "dK"), (dv, dv_r, "dV")):
+        assert torch.isfinite(got).all(), f"{name}: rows left unwritten (an item of the grid was never dispatched)"
+        U.assert_close(got.float().cpu().numpy(), ref.cpu().numpy(), "fp16", f"{name} tile-major b{b} h{h}/{hk} s{s} d{d}", sk=s)
+    assert torch.isfinite(lse).all() and (lse - lse_r).abs().max().item() <= U.LSE_TOL
+    # and the same bits as the (batch, head)-sharded call: a shard of one batch entry has fewer (batch, head) pairs, possibly the other order
+    o1, lse1 = F.fwd(q[:1], k[:1], v[:1], True)
+    assert torch.equal(o1, o[:1]) and torch.equal(lse1, lse[:1])
+
+
 def test_online_softmax_rescale_spike(gpu):
     """Force the running-max update late in the K loop (cdna guide rule 26): one key far
     larger than everything before it, at a chosen tile, for a subset of rows."""

@@ -17,7 +17,7 @@ from summarize_pmc import per_kernel, short_name  # noqa: E402
 import summarize_counters  # noqa: E402
 
 EV = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "evidence")
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r3"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r4"
 PROF = os.path.join(ROOT, "profiles")
 
 
