@@ -806,7 +806,7 @@ hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
-    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h, kp.seqlen_q, kp.n_q_tiles, kp.d == 64 ? 2 : 1);
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, kp.varlen_slots != 0 ? kp.h : (int64_t)kp.b * kp.h, kp.seqlen_q, kp.seqlen_k, kp.n_q_tiles, kp.d == 64 ? 2 : 1, (int64_t)4 * kp.seqlen_k * kp.d);
     if (bwd_use_mfma16(kp, false)) return launch_bwd_dq16(kp, dtype, s);
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
@@ -863,7 +863,7 @@ hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_split = kp.ws != nullptr ? dkdv_split(kp, kp.ws_bytes) : 1;
     kp.ws_rows = dkdv_rows(kp);
     // (key block 0 is the heaviest under a causal mask: ascending tile order is heaviest first already)
-    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0, (int64_t)kp.b * kp.h_k * kp.n_split, kp.seqlen_k, kp.n_k_tiles, kp.d == 64 ? 2 : 1);
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, (kp.varlen_slots != 0 ? (int64_t)1 : (int64_t)kp.b) * kp.h_k * kp.n_split, kp.seqlen_q, kp.seqlen_k, kp.n_k_tiles, kp.d == 64 ? 2 : 1, (int64_t)4 * kp.seqlen_q * kp.d * kp.h_ratio / kp.n_split);
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

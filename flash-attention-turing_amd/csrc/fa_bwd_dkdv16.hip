@@ -241,9 +241,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
         const int m0 = (qt_begin + cur_tile) * kKvBlockM;
         if (++cur_tile == tiles_per_head) cur_tile = 0;
         const int buf = it & 1;
+#if !FA_KV16_TOGGLE
         FA_LDS char* qbuf = smem + OFF_Q + buf * TILEB;
         FA_LDS char* dobuf = smem + OFF_DO + buf * TILEB;
         FA_LDS char* sbuf = stat + buf * STATB;
+#endif
         const bool more = (it + 1 < n_iters);
         if (more && qh == 0) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
         const float st_next = load_stat(more);

@@ -410,6 +410,38 @@ FA_DEV bool varlen_slot_lookup(const int32_t* cu, int b, uint32_t slot, int& seq
     return true;
 }
 
+// The same lookup for CAUSAL launches, heaviest items first (round 4): under the mask the work of a tile grows with its index (query tiles; key
+// blocks run the other way: block 0 is the heaviest), and a packed batch is dispatched well only if the heavy tiles of ALL sequences go first
+// (longest-processing-time order; one sequence after the other hands the compute unit that finishes a light tile the next sequence's heaviest).
+// Items are ordered by their distance L from the light end of their sequence, descending, ties by sequence index.  `tile` comes back as
+// ntiles - 1 - L: the forward / dQ kernels reverse it to L (heaviest query tile first), dK/dV takes it as is (key block 0 = L = ntiles - 1 first).
+// One sequence per lane (b <= 64), at most `tiles_max` <= 64 tiles per sequence (sequences longer than the declared max_seqlen lose their
+// surplus tiles here, which exit immediately in the kernels anyway).  Cost: a scalar loop over the levels above the item's own
+// (ballot + popcount per level), ~30 cycles each.
+constexpr uint32_t kVarlenHeavyFirst = 0xffffffffu;      // value of the kernel parameter `group_heads` that selects this lookup on a compact grid
+template <int BM>
+FA_DEV bool varlen_slot_lookup_heavy_first(const int32_t* cu, int b, uint32_t tiles_max, uint32_t slot, int& seq, int& tile, int& ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int c0 = cu[min(lane, b)], c1 = cu[min(lane + 1, b)];
+    const int t = lane < b ? min((c1 - c0 + BM - 1) / BM, (int)tiles_max) : 0;
+    uint32_t before = 0;
+    for (int L = (int)tiles_max - 1; L >= 0; --L) {
+        const uint64_t own = __ballot(t > L);                                   // sequences that have an item at level L
+        const uint32_t c = (uint32_t)__popcll((unsigned long long)own);
+        if (slot < before + c) {
+            const int r = (int)(slot - before);                                   // the r-th of them, in index order
+            const int below = __popcll((unsigned long long)(own & ((1ull << lane) - 1ull)));
+            const uint64_t pick = __ballot(((own >> lane) & 1ull) != 0 && below == r);
+            seq = __ffsll((long long)pick) - 1;
+            ntiles = __builtin_amdgcn_readlane(t, seq);
+            tile = ntiles - 1 - L;
+            return true;
+        }
+        before += c;
+    }
+    return false;                                                                 // a slack slot past the last item
+}
+
 // Common block decode: plain grid (tiles_per_bh x batch x heads, XCD-aware) or compact varlen grid (slots x heads).
 // `tile` comes back un-reversed; `ntiles` = tiles of THIS sequence (compact) or tiles_per_bh (plain) for the causal reversal.
 template <int BM>
@@ -417,6 +449,11 @@ FA_DEV bool decode_work(uint32_t id, uint32_t tiles_per_bh, uint32_t slots, cons
                         int& tile, int& batch, int& head, int& ntiles, uint32_t group_heads = 0) {
     if (slots != 0) {
         uint32_t slot, hd;
+        if (group_heads == kVarlenHeavyFirst) {                    // causal packed batch: heaviest items first, across sequences AND across heads
+            decode_block(id, slots, (uint32_t)nheads, slot, hd, (uint32_t)nheads >> 3);
+            head = (int)hd;
+            return varlen_slot_lookup_heavy_first<BM>(cu, b, tiles_per_bh, slot, batch, tile, ntiles);
+        }
         decode_block(id, slots, (uint32_t)nheads, slot, hd);
         head = (int)hd;
         return varlen_slot_lookup<BM>(cu, b, slot, batch, tile, ntiles);

@@ -64,19 +64,49 @@ struct BwdKernelParams {
 };
 
 // Dispatch order of a plain causal grid (fa_device.hpp:decode_block): how many (batch, head) streams of an XCD are walked together, tile index first.
-// Up to 4096 rows: all of them (longest-processing-time order across heads: -12..-30 % against one head after the other at 1k-4k).  Longer
-// sequences: ~2 workgroups per compute unit at a time, ceil(2 x 32 x wg_per_cu / tiles) heads (2 heads at 8k rows and head_dim 128: -1..2 %; one
-// head from 16k on = the order of rounds 1-3, where a head alone is two workgroups per unit and its K / V stays in the XCD's L2).  `wg_per_cu` =
+// Only where the mask makes the tiles UNEVEN: seqlen_k < 2 * seqlen_q (with many more keys than queries - chunked prefill, sq 1k against sk 8k -
+// every query tile sees nearly all keys, there is nothing to balance, and walking the heads together would stream each head's K / V once per
+// tile instead of once: measured +23 %).  Up to 4096 rows and keys: all heads of the XCD together (longest-processing-time order across heads:
+// -12..-30 % against one head after the other at 1k-4k).  Longer: ~2 workgroups per compute unit at a time, ceil(2 x 32 x wg_per_cu / tiles) heads (2
+// heads at 8k rows and head_dim 128: -1..2 %; one head from 16k on = the order of rounds 1-3, where a head alone is two workgroups per unit and
+// its K / V stays in the XCD's L2).  `tiles` / `rows` are those of the axis the grid walks (query tiles; key blocks for dK/dV), `wg_per_cu` the
 // workgroups of this kernel a compute unit holds at a time (2 for the narrow head_dim-64 kernels); an XCD has 32 compute units.
 // FA_CAUSAL_ORDER 0 = one head after the other everywhere (A/B).  profiles/r4_causal_tile_order_ab.log, r4_causal_tile_order_long_ab.log, r4_causal_group_order_ab.log
 #ifndef FA_CAUSAL_ORDER
 #define FA_CAUSAL_ORDER 1
 #endif
-inline uint32_t causal_group_heads(bool causal, bool compact_grid, int64_t n_bh, int64_t rows, int64_t tiles, int wg_per_cu) {
-    if (FA_CAUSAL_ORDER == 0 || !causal || compact_grid || (n_bh & 7) != 0 || tiles < 2) return 0u;
+// Packed batches on the compact grid (`compact_b` = number of sequences, 0 = plain grid): heaviest items first across sequences and heads
+// (fa_device.hpp:varlen_slot_lookup_heavy_first) when there is one sequence per lane and at most 64 tiles per sequence.
+#ifndef FA_VARLEN_HEAVY_FIRST
+#define FA_VARLEN_HEAVY_FIRST 1
+#endif
+// FA_CAUSAL_GROUP_MB: up to 4096 rows the heads of an XCD are walked together only as far as the streams they re-read (K and V of a head for the
+// forward / dQ, Q and dO for dK/dV) stay in reach of the cache behind the L2s: 16 x 32 heads at 2k rows in ONE group stream 4 GB per launch and
+// run at 0.91 of the head-after-head time where groups of 12-24 MiB reach 0.79-0.80 (profiles/r4_causal_group_footprint_ab.log).
+#ifndef FA_CAUSAL_GROUP_MB
+#define FA_CAUSAL_GROUP_MB 16
+#endif
+inline uint32_t causal_group_heads(bool causal, int64_t compact_b, int64_t n_bh, int64_t seqlen_q, int64_t seqlen_k, int64_t tiles, int wg_per_cu,
+                                   int64_t stream_bytes_per_head = 0) {
+    if (FA_CAUSAL_ORDER == 0 || !causal || tiles < 2 || seqlen_k >= 2 * seqlen_q) return 0u;
+    if (compact_b != 0)      // (n_bh = heads of the grid here: the XCD rule needs a multiple of 8)
+        return (FA_VARLEN_HEAVY_FIRST && compact_b <= 64 && tiles <= 64 && (n_bh & 7) == 0) ? 0xffffffffu : 0u;
+    if ((n_bh & 7) != 0) return 0u;
     const int64_t per_xcd = n_bh >> 3;
-    if (rows <= 4096) return (uint32_t)per_xcd;
-    const int64_t g = (2 * 32 * (int64_t)wg_per_cu + tiles - 1) / tiles;
+    int64_t g = (2 * 32 * (int64_t)wg_per_cu + tiles - 1) / tiles;                  // ~2 workgroups per compute unit
+    if (seqlen_q <= 4096 && seqlen_k <= 4096) {
+        // all heads together, as far as their streams fit; groups of equal size (a short last group runs unbalanced)
+        int64_t cap = stream_bytes_per_head > 0 ? ((int64_t)FA_CAUSAL_GROUP_MB << 20) / stream_bytes_per_head : per_xcd;
+        if (cap < g) cap = g;
+        if (cap >= per_xcd) return (uint32_t)per_xcd;
+        // equal groups (a short last group runs unbalanced: 8 % in profiles/r4_causal_group_order_ab.log): the largest divisor of the heads per
+        // XCD within the cap, unless that is less than half of it - then near-equal groups of ceil(heads / groups)
+        int64_t div = 1;
+        for (int64_t c = cap; c >= 1; --c)
+            if (per_xcd % c == 0) { div = c; break; }
+        const int64_t n_groups = (per_xcd + cap - 1) / cap;
+        g = 2 * div >= cap ? div : (per_xcd + n_groups - 1) / n_groups;
+    }
     return g <= 1 ? 0u : (uint32_t)(g < per_xcd ? g : per_xcd);
 }
 

@@ -222,14 +222,16 @@ def test_d64_forward_tile_shapes(gpu, sq, sk):
         assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
 
 
-@pytest.mark.parametrize("b,h,hk,s,d", [(2, 12, 12, 1280, 128), (1, 8, 8, 2304, 64), (3, 8, 2, 1100, 128), (1, 16, 16, 4200, 128), (2, 5, 5, 1300, 128)])
+@pytest.mark.parametrize("b,h,hk,s,d", [(2, 12, 12, 1280, 128), (1, 8, 8, 2304, 64), (3, 8, 2, 1100, 128), (1, 16, 16, 4200, 128), (2, 5, 5, 1300, 128),
+                                        (24, 8, 8, 2048, 128), (23, 8, 8, 2048, 128)])
 def test_causal_grid_walked_tile_index_first(gpu, b, h, hk, s, d):
     """Round 4: plain causal grids are dispatched in groups of (batch, head) streams, tile index first inside a group, when batch * heads is a
     multiple of 8 (fa_device.hpp:decode_block, fa_params.hpp:causal_group_heads): all heads of an XCD together up to 4096 rows, ~2 workgroups per
     compute unit beyond.  The block-id -> (tile, batch, head) map must still hit every item exactly once - a missed item leaves its rows
     unwritten: the outputs start as NaN here and every tensor is checked against fp32 math.  The 4200-row case is on the grouped side of the
     4096-row switch (16 query tiles -> groups of 4 heads, only 2 per XCD here: a partial group; its 33 key blocks of dK/dV -> groups of 2);
-    batch x heads = 24, 8, 24, 16 take the new path, 10 (not a multiple of 8) the old one."""
+    batch x heads = 24, 8, 24, 16 take the new path, 10 (not a multiple of 8) the old one; the two 2048-row batches have 24 and 23 heads per XCD,
+    more than the 16 MiB footprint cap lets walk together: groups of 12 (a divisor) and of 12 + 11 (none within reach)."""
     import flash_attn_turing as F
     from flash_attn_turing import capi
 

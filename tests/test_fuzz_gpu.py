@@ -260,9 +260,34 @@ def test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case):
     d = int(rng.choice([64, 128]))
     dt = ("fp16", "bf16")[case % 2]
     causal = bool(case % 3 == 0)
+    _compact_vs_plain(gpu, lens, h, hk, d, dt, causal, 15000 + case, f"case {case}")
+
+
+@pytest.mark.parametrize("name,lens,h,hk", [
+    ("long first", [2048] * 3 + [0, 1, 40, 300, 64, 129] * 5, 8, 8),
+    ("long last, 64 sequences", [17, 0, 256, 257, 1, 90] * 10 + [1500, 0, 2600, 700], 16, 4),
+    ("65 sequences: one per lane no longer fits, the sequence-major lookup serves", [33] * 60 + [1500, 0, 2600, 700, 5], 8, 2),
+    ("one sequence of exactly 64 query tiles = 128 key blocks (dK/dV falls back, forward and dQ do not)", [16384, 300, 0, 64], 8, 8),
+    ("65 query tiles: fallback for every kernel", [16400, 300], 8, 8),
+    ("equal lengths", [512] * 12, 24, 24),
+    ("a single sequence", [1000], 8, 8),
+])
+@pytest.mark.parametrize("d", [128, 64])
+def test_varlen_causal_heavy_first_lookup_is_bit_identical_to_plain_grid(gpu, name, lens, h, hk, d):
+    """Round 4: a CAUSAL packed batch on the compact grid is dispatched heaviest items first across sequences and heads
+    (fa_device.hpp:varlen_slot_lookup_heavy_first: heads a multiple of 8, at most 64 sequences, at most 64 tiles per sequence).  Only the order in
+    which workgroups find their (sequence, tile) changes: every output must equal the plain grid's bit for bit, on both sides of each limit."""
+    _compact_vs_plain(gpu, lens, h, hk, d, "fp16" if d == 128 else "bf16", True, 777 + len(lens), name)
+
+
+def _compact_vs_plain(gpu, lens, h, hk, d, dt, causal, seed, tag):
+    import ctypes
+
+    from flash_attn_turing import capi
+
     tdt = U.torch_dtype(dt)
     tot, b, mx = sum(lens), len(lens), max(lens)
-    gen = torch.Generator(device="cpu").manual_seed(15000 + case)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
     q, do = (torch.randn(tot, h, d, generator=gen).to(gpu, tdt) for _ in range(2))
     k, v = (torch.randn(tot, hk, d, generator=gen).to(gpu, tdt) for _ in range(2))
     cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(gpu)
@@ -286,4 +311,4 @@ def test_varlen_compact_grid_is_bit_identical_to_plain_grid(gpu, case):
         res[total] = (o, lse, dq, dk, dv)
     for total in (tot, tot + 1000):
         for g, r, name in zip(res[total], res[0], ("O", "LSE", "dQ", "dK", "dV")):
-            assert torch.equal(g, r), f"{name} differs between compact (total={total}) and plain grid [case {case}: lens {lens} h{h}/{hk} d{d} {dt} causal={causal}]"
+            assert torch.equal(g, r), f"{name} differs between compact (total={total}) and plain grid [{tag}: lens {lens} h{h}/{hk} d{d} {dt} causal={causal}]"

@@ -88,8 +88,13 @@ def main():
                                   ("1 x 8192 + 63 x 64", [8192] + [64] * 63, (1, 8192)),
                                   ("2 x 4096 + 30 x 128", [4096] * 2 + [128] * 30, (2, 4096)),
                                   ("4 x 2048 + 60 x 32", [2048] * 4 + [32] * 60, (4, 2048)),
+                                  ("60 x 32 + 4 x 2048 (long ones last)", [32] * 60 + [2048] * 4, (4, 2048)),
+                                  ("8 x 1024 .. 8 x 128 mixed", [1024, 128, 512, 256] * 8, None),
                                   ("16 x 512 (equal, control)", [512] * 16, (16, 512))):
             vf, vb, cf, cb, same = run(lengths, h, hk, d, dt, causal)
+            if eq is None:
+                print(f"{('causal ' if causal else 'non-causal ') + name:44s} plain {vf:7.3f} {vb:7.3f} | compact {cf:7.3f} {cb:7.3f} | bit-identical {same}", flush=True)
+                continue
             df, db = dense(eq[0], eq[1], h, hk, d, dt, causal)
             print(f"{('causal ' if causal else 'non-causal ') + name:44s} plain {vf:7.3f} {vb:7.3f} | compact {cf:7.3f} {cb:7.3f} | dense b{eq[0]} s{eq[1]} {df:7.3f} {db:7.3f} | "
                   f"plain/dense {vf / df:4.2f} {vb / db:4.2f}  compact/dense {cf / df:4.2f} {cb / db:4.2f}  bit-identical {same}", flush=True)
