@@ -43,6 +43,16 @@ constexpr float kPpDeferLog2 = 6.0f;
 #ifndef FA_PP16_MFMA_ROWSUM
 #define FA_PP16_MFMA_ROWSUM 1
 #endif
+// FA_PP16_ROLE_DMA (round 4): in the unrolled steady loop the waves of group A (0-3) move the K tiles and those of group B (4-7) the V tiles,
+// four 1-KiB pieces each, instead of two pieces of both.  Why: with symmetric roles a tile requested in S(u) has to be complete when S(u) ends
+// (group B runs one phase behind group A: its pieces of K(u+2) are read by group A two barriers later, and the first fragments of V(u+1) are
+// prefetched one phase after their request) - one softmax phase, ~0.8 us, to cover an L2 miss.  With the roles split, K(u+2) requested in A's S(u)
+// is first read in A's M(u+2), and V(u+2) requested in B's S(u) is first touched by group A's prefetch at the end of A's S(u+2): both can stay in
+// flight for a whole tile period and are retired by a COUNTED wait at the end of the requesting group's NEXT softmax phase (step_c).  Requests
+// are unconditional there (a tile past the sequence's end is a zero fill, one past the mask's end is fetched and never read).
+#ifndef FA_PP16_ROLE_DMA
+#define FA_PP16_ROLE_DMA 1
+#endif
 #ifndef FA_PP16_EXACT_TILES
 #define FA_PP16_EXACT_TILES 16
 #endif
@@ -139,6 +149,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     }
     const uint32_t dma_loff = (uint32_t)wave * DPW * 1024;       // wave-uniform LDS offset of this wave's pieces
     const uint32_t lds_k0 = lds_addr(kring) + dma_loff, lds_v0 = lds_addr(vring) + dma_loff;
+#if FA_PP16_ROLE_DMA
+    constexpr int RPW = BN * SLOTS / 256;     // pieces per wave and tile when four waves move a whole tile: 4
+    const uint32_t r_rowb = group ? v_rowb : k_rowb;
+    uint32_t dma_goff_r[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int chunk = ((wave & 3) * RPW + i) * 64 + lane, row = chunk / SLOTS, phys = chunk % SLOTS;
+        dma_goff_r[i] = row * r_rowb + lds_tile_logical_slot<D>(row, phys) * 16;
+    }
+    const uint32_t lds_r0 = (group ? lds_addr(vring) : lds_addr(kring)) + (uint32_t)(wave & 3) * RPW * 1024;
+#endif
     // K row reads (A of S^T = K Q^T): key block kb, k-step ks -> row 16*kb + 4*kPi2[gi] + r (i = n16 = 4*gi + r), 16-byte slot 4*ks + kPi[g]
     uint32_t k_rd[KS];
     {
@@ -187,6 +208,14 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
     };
+
+#if FA_PP16_ROLE_DMA
+    const srd_t r_srd = group ? v_srd : k_srd;
+    auto dma_role_tile = [&](int t, int slot) __attribute__((always_inline)) {      // group A: K(t), group B: V(t)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) dma16_to_lds_hidden<false>(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb + dma_goff_r[i], lds_r0 + slot * TILEB + i * 1024);
+    };
+#endif
 
     // ---- prologue: K(0), V(0), K(1) into the rings (past-the-end tiles arrive as zeros) ---------------
     if (n_tiles > 0) {
@@ -494,16 +523,32 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             constexpr int S_UM1 = decltype(um1)::value, S_U = decltype(u0)::value, S_UP1 = decltype(up1)::value;
             m_phase(S_UM1, S_U, lsc);
             __syncthreads();
+#if FA_PP16_ROLE_DMA
+            // group A: K(u+2) -> the slot K(u-1) left (last read in M(u-1), which group B finished one barrier ago);
+            // group B: V(u+2) -> the slot V(u-1) left (last read in M(u), which group B itself has just finished and group A one phase earlier).
+            // Retired: the tile requested one softmax phase ago (K(u+1) / V(u+1)), by count - this phase's four pieces stay in flight.
+            dma_role_tile(uu + 2, S_UM1);
+            softmax_step(uu, no{}, no{}, mlc);
+            m_prefetch(S_U, S_UP1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
+            __syncthreads();
+#else
             if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
             if (uu + 1 < n_tiles) dma_v_tile(v_srd, uu + 1, S_UP1);
             softmax_step(uu, no{}, no{}, mlc);
             m_prefetch(S_U, S_UP1);
             end_s_phase();
+#endif
         };
         using i0 = std::integral_constant<int, 0>;
         using i1 = std::integral_constant<int, 1>;
         using i2 = std::integral_constant<int, 2>;
         u = 1;
+#if FA_PP16_ROLE_DMA
+        // entering the role-split loop: K(2) was requested by tile 0's iteration, V(2) by nobody yet (the symmetric scheme runs V one tile behind K)
+        const bool role_loop = n_main >= 4;
+        if (role_loop && group == 1) dma_role_tile(2, 2);
+#endif
         // ring slot of tile u is u % 3: three steps per trip make every slot a constant
         constexpr int kExact = ML ? 1 + 3 * ((FA_PP16_EXACT_TILES + 1) / 3) : 0;      // first MFMA-summed tile: start of a trip (16 for the default)
         if constexpr (ML) {
@@ -531,6 +576,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 step_c(u + 2, i2{}, i0{}, i1{}, no{}, no{});
             }
         }
+#if FA_PP16_ROLE_DMA
+        // leaving it: this wave's last request (one tile ahead of what the symmetric code below assumes; that code requests the tile again, the
+        // same bytes into the same slot) is retired here; the next barrier publishes it long before its first read
+        if (role_loop) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         for (; u < n_main; ++u) {                 // the last one or two steady-state tiles
             m_phase(ring_um1, ring_u, prev_ml);
             __syncthreads();
