@@ -56,12 +56,13 @@ constexpr float kPpDeferLog2 = 6.0f;
 //              every non-causal length (1-8 %) and for short causal ones;
 //   128 keys - the D = 128 structure (16 KiB tiles, 32 MFMAs per matrix phase, one workgroup per CU, x3-unrolled loop, optimistic
 //              softmax also under the mask): the per-tile costs that do not shrink with D (two barriers, DMA pieces at ~110 cycles
-//              each, the phase hand-over) weigh half as much; 5-9 % faster under a causal mask from 2k keys on.
+//              each, the phase hand-over) weigh half as much; 5-9 % faster under a causal mask from 2k keys on in round 3, only from
+//              16k keys on since the causal dispatch order of round 4 (fa_params.hpp:causal_group_heads) took the imbalance away.
 // Measured ladder 256 .. 16k, both shapes, causal or not: profiles/r3_fwd_d64_tile_ab.log.  -DFA_FWD_D64_BN=64 / 128 pins one shape (A/B).
 #ifndef FA_FWD_D64_BN
 #define FA_FWD_D64_BN 0
 #endif
-constexpr int kFwdD64WideMinKeys = 2048;
+constexpr int kFwdD64WideMinKeys = 16384;     // (round 3: 2048.  With the round-4 causal dispatch order the 64-key shape is ahead up to 8k: profiles/r4_fwd_d64_shapes_after_reorder_ab.log)
 // Matrix phase = NPV P*V steps, then NQK QK^T steps.  P*V step j -> (output block db = j % DB, key sub-tile ts = j / DB): consecutive
 // MFMAs go to different accumulators (per accumulator the ts order, hence the result, is unchanged; 0.3-0.5 % over db-major at D = 128;
 // alternating P*V and QK^T steps measured the same, profiles/r2_fwd_step_order_ab.log).

@@ -201,11 +201,11 @@ def test_bf16_backward_medium(gpu):
         assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
 
 
-@pytest.mark.parametrize("sq,sk", [(2048, 2048), (2500, 2500), (1000, 3000), (2047, 2047), (300, 2048)])
+@pytest.mark.parametrize("sq,sk", [(2048, 2048), (2500, 2500), (1000, 3000), (2047, 2047), (300, 2048), (300, 16384), (1100, 16500), (700, 16383)])
 def test_d64_forward_tile_shapes(gpu, sq, sk):
-    """head_dim 64 dispatches between two forward tile shapes (fa_fwd_pp.hip: 128-key tiles under a causal mask from 2048 keys on,
-    64-key tiles otherwise): both sides of the switch, ragged tails and sq != sk, forward values and LSE against fp32 math, and the
-    backward fed by them."""
+    """head_dim 64 dispatches between two forward tile shapes (fa_fwd_pp.hip: 128-key tiles under a causal mask from 16384 keys on - 2048 until
+    round 4 - 64-key tiles otherwise): both sides of the old and of the new switch, ragged tails and sq != sk, forward values and LSE against fp32
+    math, and the backward fed by them."""
     import flash_attn_turing as F
 
     gen = torch.Generator(device="cpu").manual_seed(sq * 7 + sk)

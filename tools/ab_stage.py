@@ -32,6 +32,9 @@ CONFIGS = {
     "fp16 d128 1k causal b32": (32, 1024, 32, 32, 128, F16, True),
     "fp16 d128 4k causal b8": (8, 4096, 32, 32, 128, F16, True),
     "fp16 d64 2k causal b16": (16, 2048, 32, 32, 64, F16, True),
+    "fp16 d64 4k causal": (4, 4096, 32, 32, 64, F16, True),
+    "fp16 d64 16k causal": (4, 16384, 32, 32, 64, F16, True),
+    "bf16 d64 8k causal": (4, 8192, 32, 32, 64, BF16, True),
     "fp16 d64 2k causal": (4, 2048, 32, 32, 64, F16, True),
     "fp16 d128 512 causal": (4, 512, 32, 32, 128, F16, True),
     "fp16 d64 8k": (4, 8192, 32, 32, 64, F16, False),
