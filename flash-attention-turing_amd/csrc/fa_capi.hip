@@ -114,10 +114,14 @@ double fa_fwd_bytes(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, in
 const char* fa_fwd_kernel_name(int32_t d) { return fa::fwd_kernel_name(d); }
 int32_t fa_set_kernel_policy(int32_t policy) { return fa::set_kernel_policy(policy); }
 const char* fa_kernel_name(int32_t stage, int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal) {
+    return fa_kernel_name_dtype(stage, FA_FP16, b, seqlen_q, seqlen_k, h, d, is_causal);
+}
+const char* fa_kernel_name_dtype(int32_t stage, int32_t dtype, int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal) {
+    if (dtype != FA_FP16 && dtype != FA_BF16) return "";
     if (stage == FA_STAGE_FWD) {
         fa::FwdKernelParams kp{};
         kp.b = b; kp.seqlen_q = seqlen_q; kp.seqlen_k = seqlen_k; kp.h = h; kp.d = d; kp.is_causal = is_causal;
-        return fa::fwd_kernel_name_for(kp);
+        return fa::fwd_kernel_name_for(kp, dtype);
     }
     if (stage != FA_STAGE_DQ && stage != FA_STAGE_DKDV) return "";
     fa::BwdKernelParams kp{};

@@ -554,19 +554,27 @@ constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 22;             // 2048 x 2
 constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 24;       // 4096 x 4096
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
 
-static bool use_mfma16(const FwdKernelParams& kp) {
+// head_dim 64 (round 4): fp16 through the 16x16x32 kernel with 128-key tiles once its row sums ride the matrix pipe - at head_dim 64 the softmax
+// VALU work per MFMA is twice that of head_dim 128 and the pipe is half idle, so the adds it takes over are worth more: -2 % at 4k, -5 % at 8k / 16k
+// non-causal, -3.6 % at 8k and -5.3 % at 16k causal; +9..24 % at causal 2k-4k, +2 % at non-causal 2k, and bf16 (VALU row sums) +1..2 % everywhere
+// (profiles/r4_fwd_d64_mfma16_ab.log; round 3 without the MFMA row sums: -1.4 % at best, profiles/r3_fwd_mfma16_d64_probe.log).
+constexpr int64_t kFwdD64Mfma16MinPairs = (int64_t)1 << 24;          // 4096 x 4096
+constexpr int64_t kFwdD64Mfma16MinPairsCausal = (int64_t)1 << 26;    // 8192 x 8192
+static bool use_mfma16(const FwdKernelParams& kp, int dtype) {
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
-    if (kp.d != 128 || policy == 0) return false;
+    if (policy == 0 || (kp.d != 128 && kp.d != 64)) return false;
     if (policy == 1) return true;
+    if (kp.d == 64) return dtype == 0 && (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kFwdD64Mfma16MinPairsCausal : kFwdD64Mfma16MinPairs);
     // (packed sequences: max_seqlen_q x max_seqlen_k; never total_q - the optional hint must not change which kernel, hence which bits,
     // a call gets: tests/test_fuzz_gpu.py compares the compact and the plain varlen grid bit for bit)
     return (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kFwdMfma16MinPairsCausal : kFwdMfma16MinPairs);
 }
 
 // the kernel that serves the LARGE problems of a head dimension (what a profile of the BASELINE configurations shows)
-const char* fwd_kernel_name(int d) { return d == 128 && g_fwd_policy.load(std::memory_order_relaxed) != 0 ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
+// (head_dim 64: of fp16 inputs; bf16 stays on fa_fwd_pp_kernel unless the 16x16x32 set is pinned - fwd_kernel_name_for answers per dtype)
+const char* fwd_kernel_name(int d) { return (d == 128 || d == 64) && g_fwd_policy.load(std::memory_order_relaxed) != 0 ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
 
-const char* fwd_kernel_name_for(const FwdKernelParams& kp) { return use_mfma16(kp) ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
+const char* fwd_kernel_name_for(const FwdKernelParams& kp, int dtype) { return use_mfma16(kp, dtype) ? "fa_fwd_pp16_kernel" : "fa_fwd_pp_kernel"; }
 
 // (Round 4 built a third head_dim-128 forward, one wave per SIMD with 64 query rows per wave and O / Q in asm-owned accumulation registers,
 // fa_fwd_w4.hip: bit-identical to fa_fwd_pp16 and 7-12 % slower - a lone wave cannot issue 16x16x32 MFMAs at the pipe's rate.  Not in the
@@ -576,9 +584,9 @@ hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     // (head_dim 64 runs two workgroups per compute unit except in its 128-key causal shape, launch_pp_t)
-    const int wg_per_cu = (kp.d == 64 && !(FA_FWD_D64_BN != 0 ? FA_FWD_D64_BN == 128 : (kp.is_causal && kp.seqlen_k >= kFwdD64WideMinKeys))) ? 2 : 1;
+    const int wg_per_cu = (kp.d == 64 && !use_mfma16(kp, dtype) && !(FA_FWD_D64_BN != 0 ? FA_FWD_D64_BN == 128 : (kp.is_causal && kp.seqlen_k >= kFwdD64WideMinKeys))) ? 2 : 1;
     kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, kp.varlen_slots != 0 ? kp.h : (int64_t)kp.b * kp.h, kp.seqlen_q, kp.seqlen_k, kp.n_q_tiles, wg_per_cu, (int64_t)4 * kp.seqlen_k * kp.d);
-    if (use_mfma16(kp)) return launch_fwd_pp16(kp, dtype, grid, stream);
+    if (use_mfma16(kp, dtype)) return launch_fwd_pp16(kp, dtype, grid, stream);
     if (dtype == 0) return kp.d == 128 ? launch_pp_t<_Float16, 128>(kp, grid, stream) : launch_pp_t<_Float16, 64>(kp, grid, stream);
     return kp.d == 128 ? launch_pp_t<__bf16, 128>(kp, grid, stream) : launch_pp_t<__bf16, 64>(kp, grid, stream);
 }

@@ -376,12 +376,24 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 // largest packed P of the lane, both query columns: positive fp16 / bf16 bit patterns order like unsigned integers, and
                 // v_pk_maximum3_f16 (IEEE maximum: NaN wins) on bf16 bits is monotone as long as they read as finite fp16, i.e. below 2^121;
                 // anything above, Inf and NaN come out as a pattern above kBits64 as well.
-                static_assert(NC == 2, "guard written for two 32-key chunks per tile");
-                uint32_t t0 = pk_max3_f16_bits(pf[0][0].x, pf[0][0].y, pf[0][0].z), t1 = pk_max3_f16_bits(pf[0][1].x, pf[0][1].y, pf[0][1].z);
-                t0 = pk_max3_f16_bits(t0, pf[0][0].w, pf[1][0].x); t1 = pk_max3_f16_bits(t1, pf[0][1].w, pf[1][1].x);
-                t0 = pk_max3_f16_bits(t0, pf[1][0].y, pf[1][0].z); t1 = pk_max3_f16_bits(t1, pf[1][1].y, pf[1][1].z);
-                t0 = pk_max3_f16_bits(t0, pf[1][0].w, t1);
-                t0 = pk_max3_f16_bits(t0, pf[1][1].w, pf[1][1].w);
+                uint32_t t0, t1;
+                if constexpr (NC == 2) {
+                    t0 = pk_max3_f16_bits(pf[0][0].x, pf[0][0].y, pf[0][0].z); t1 = pk_max3_f16_bits(pf[0][1].x, pf[0][1].y, pf[0][1].z);
+                    t0 = pk_max3_f16_bits(t0, pf[0][0].w, pf[1][0].x); t1 = pk_max3_f16_bits(t1, pf[0][1].w, pf[1][1].x);
+                    t0 = pk_max3_f16_bits(t0, pf[1][0].y, pf[1][0].z); t1 = pk_max3_f16_bits(t1, pf[1][1].y, pf[1][1].z);
+                    t0 = pk_max3_f16_bits(t0, pf[1][0].w, t1);
+                    t0 = pk_max3_f16_bits(t0, pf[1][1].w, pf[1][1].w);
+                } else {                                              // any chunk count: one chain per query column, two words a step
+                    t0 = pf[0][0].x; t1 = pf[0][1].x;
+                    t0 = pk_max3_f16_bits(t0, pf[0][0].y, pf[0][0].z); t1 = pk_max3_f16_bits(t1, pf[0][1].y, pf[0][1].z);
+#pragma unroll
+                    for (int cch = 1; cch < NC; ++cch) {
+                        t0 = pk_max3_f16_bits(t0, pf[cch - 1][0].w, pf[cch][0].x); t1 = pk_max3_f16_bits(t1, pf[cch - 1][1].w, pf[cch][1].x);
+                        t0 = pk_max3_f16_bits(t0, pf[cch][0].y, pf[cch][0].z); t1 = pk_max3_f16_bits(t1, pf[cch][1].y, pf[cch][1].z);
+                    }
+                    t0 = pk_max3_f16_bits(t0, pf[NC - 1][0].w, pf[NC - 1][1].w);
+                    t0 = pk_max3_f16_bits(t0, t1, t1);
+                }
                 const uint32_t both = max(t0, t0 << 16);          // top half = the larger of the two packed values
                 return both > ((LP<T>::kBits64 << 16) | 0xffffu);
             } else {
@@ -550,7 +562,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         if (role_loop && group == 1) dma_role_tile(2, 2);
 #endif
         // ring slot of tile u is u % 3: three steps per trip make every slot a constant
-        constexpr int kExact = ML ? 1 + 3 * ((FA_PP16_EXACT_TILES + 1) / 3) : 0;      // first MFMA-summed tile: start of a trip (16 for the default)
+        constexpr int kExactTiles = FA_PP16_EXACT_TILES * 64 / BN;      // (counted in 64-key tiles: the same 1024 keys for any tile width)
+        constexpr int kExact = ML ? 1 + 3 * ((kExactTiles + 1) / 3) : 0;      // first MFMA-summed tile: start of a trip (16 for the default)
         if constexpr (ML) {
             for (; u + 3 <= n_main && u + 3 <= kExact; u += 3) {      // exactly summed tiles
                 step_c(u, i0{}, i1{}, i2{}, no{}, no{});
@@ -601,6 +614,16 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
+    if (kp.d == 64) {      // 128-key tiles: the same 16 KiB tile images, one workgroup per CU
+        if (dtype == 0) {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 64, true, 128>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+            else hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 64, false, 128>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        } else {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 64, true, 128>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+            else hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 64, false, 128>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        }
+        return hipGetLastError();
+    }
     if (dtype == 0) {
         if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, true, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
         else hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, false, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);

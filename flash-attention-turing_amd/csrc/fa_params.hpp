@@ -116,7 +116,7 @@ int64_t dkdv_workspace_bytes(const BwdKernelParams& kp, int32_t n_split);
 
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream);
 const char* fwd_kernel_name(int d);
-const char* fwd_kernel_name_for(const FwdKernelParams& kp);                 // the kernel launch_fwd would pick for this problem
+const char* fwd_kernel_name_for(const FwdKernelParams& kp, int dtype);                 // the kernel launch_fwd would pick for this problem
 const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv);      // ... launch_bwd_dq / launch_bwd_dkdv
 int set_kernel_policy(int policy);      // FA_POLICY_* of the public header; returns the previous one, -1 for an unknown value
 int kernel_policy();

@@ -59,11 +59,15 @@ def set_kernel_policy(policy) -> str:
     return next(k for k, v in names.items() if v == prev)
 
 
-def kernel_name(stage, batch, seqlen_q, seqlen_k, nheads, head_dim, causal) -> str:
-    """the kernel a launch of this shape goes to under the current policy; stage in {"fwd", "dq", "dkdv"} (C ABI fa_kernel_name)"""
+def kernel_name(stage, batch, seqlen_q, seqlen_k, nheads, head_dim, causal, dtype=None) -> str:
+    """the kernel a launch of this shape goes to under the current policy; stage in {"fwd", "dq", "dkdv"}; dtype torch.float16 (default) /
+    torch.bfloat16 or "fp16" / "bf16" (C ABI fa_kernel_name_dtype)"""
     from . import capi
 
-    return capi.kernel_name(stage, batch, seqlen_q, seqlen_k, nheads, head_dim, causal)
+    name = {None: "fp16", _torch.float16: "fp16", _torch.bfloat16: "bf16", "fp16": "fp16", "bf16": "bf16"}.get(dtype)
+    if name is None:
+        raise ValueError("dtype must be torch.float16 or torch.bfloat16")
+    return capi.kernel_name(stage, batch, seqlen_q, seqlen_k, nheads, head_dim, causal, name)
 
 
 def abi_version() -> int:

@@ -106,6 +106,8 @@ def lib():
         L.fa_fwd_kernel_name.restype = ctypes.c_char_p
         L.fa_kernel_name.argtypes = [_i32] * 7
         L.fa_kernel_name.restype = ctypes.c_char_p
+        L.fa_kernel_name_dtype.argtypes = [_i32] * 8
+        L.fa_kernel_name_dtype.restype = ctypes.c_char_p
         L.fa_set_kernel_policy.argtypes = [_i32]
         L.fa_set_kernel_policy.restype = _i32
         _lib = L
@@ -123,9 +125,12 @@ def fwd_kernel_name(d) -> str:
 STAGES = {"fwd": 0, "dq": 1, "dkdv": 2}
 
 
-def kernel_name(stage, b, seqlen_q, seqlen_k, h, d, causal) -> str:
-    """fa_kernel_name: the kernel a launch of this shape goes to under the current policy (stage: "fwd", "dq", "dkdv")"""
-    return lib().fa_kernel_name(STAGES[stage], int(b), int(seqlen_q), int(seqlen_k), int(h), int(d), int(bool(causal))).decode()
+DTYPES = {"fp16": 0, "bf16": 1}
+
+
+def kernel_name(stage, b, seqlen_q, seqlen_k, h, d, causal, dtype="fp16") -> str:
+    """fa_kernel_name_dtype: the kernel a launch of this shape goes to under the current policy (stage: "fwd", "dq", "dkdv"; dtype "fp16" / "bf16")"""
+    return lib().fa_kernel_name_dtype(STAGES[stage], DTYPES[dtype], int(b), int(seqlen_q), int(seqlen_k), int(h), int(d), int(bool(causal))).decode()
 
 
 POLICY_MFMA32, POLICY_MFMA16, POLICY_AUTO = 0, 1, 2

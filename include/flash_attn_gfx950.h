@@ -203,7 +203,8 @@ double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, in
 /* Name of the forward kernel the library dispatches LARGE problems of this head_dim to (what a profiler's kernel trace of the
  * BASELINE configurations will show; lets a benchmark tie a committed PMC profile to the kernel that actually ran).  head_dim 128
  * has two kernels: problems of seqlen_q * seqlen_k < 2^22 (2^24 under a causal mask) run fa_fwd_pp_kernel, larger ones
- * fa_fwd_pp16_kernel. */
+ * fa_fwd_pp16_kernel; head_dim 64 likewise for fp16 inputs from 2^24 (2^26 under a causal mask) - the answer given here - while bf16
+ * inputs stay on fa_fwd_pp_kernel at every size (fa_kernel_name_dtype answers per dtype). */
 const char* fa_fwd_kernel_name(int32_t d);
 /* head_dim 128 has two sets of kernels, tiled for v_mfma_f32_32x32x16 and for v_mfma_f32_16x16x32.  Both meet the same tolerances;
  * they differ in speed only: the 16x16x32 shape draws less power per FLOP and wins where the chip's power cap binds (long launches),
@@ -212,7 +213,9 @@ const char* fa_fwd_kernel_name(int32_t d);
  * (batch, head) shard of a problem gets the bits the whole problem gets (one exception: dK / dV of a GQA / MQA call that is given a
  * workspace - how far a head group is split, hence the order its partial sums are added in, follows the launch's workgroup count and the
  * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit); FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
- * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 is not affected.  The reference has no counterpart. */
+ * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has one backward set (not affected) and, since round 4,
+ * both forward kernels: FA_POLICY_AUTO sends fp16 problems from 2^24 pairs per head (2^26 causal) to the 16x16x32 one, whose softmax row sums
+ * ride the matrix pipe (-2..5 %), and keeps bf16 on the 32x32x16 one; the pinned policies apply to both dtypes.  The reference has no counterpart. */
 #define FA_POLICY_MFMA32 0
 #define FA_POLICY_MFMA16 1
 #define FA_POLICY_AUTO 2
@@ -223,6 +226,9 @@ int32_t fa_set_kernel_policy(int32_t policy);
 #define FA_STAGE_DQ 1
 #define FA_STAGE_DKDV 2
 const char* fa_kernel_name(int32_t stage, int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal);
+/* The same per input dtype (enum fa_dtype; fa_kernel_name answers for FA_FP16): the only choice that depends on it is the head_dim-64 forward
+ * under FA_POLICY_AUTO.  "" for an unknown stage or dtype. */
+const char* fa_kernel_name_dtype(int32_t stage, int32_t dtype, int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal);
 /* Peak shader clock of `device` in kHz (hipDeviceAttributeClockRate), or a negative HIP error code: with 256 CUs x 4096 FLOP/clk/CU
  * it derives the dense fp16 MFMA peak a benchmark quotes (256 x 2.4 GHz x 4096 = 2.5 PFLOP/s). */
 int fa_device_clock_khz(int32_t device);

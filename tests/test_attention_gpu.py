@@ -201,11 +201,12 @@ def test_bf16_backward_medium(gpu):
         assert (lse - lse_r).abs().max().item() <= U.LSE_TOL
 
 
-@pytest.mark.parametrize("sq,sk", [(2048, 2048), (2500, 2500), (1000, 3000), (2047, 2047), (300, 2048), (300, 16384), (1100, 16500), (700, 16383)])
+@pytest.mark.parametrize("sq,sk", [(2048, 2048), (2500, 2500), (1000, 3000), (2047, 2047), (300, 2048), (300, 16384), (1100, 16500), (700, 16383),
+                                   (4096, 4096), (4200, 4300), (4000, 4100), (8192, 8200)])
 def test_d64_forward_tile_shapes(gpu, sq, sk):
     """head_dim 64 dispatches between two forward tile shapes (fa_fwd_pp.hip: 128-key tiles under a causal mask from 16384 keys on - 2048 until
-    round 4 - 64-key tiles otherwise): both sides of the old and of the new switch, ragged tails and sq != sk, forward values and LSE against fp32
-    math, and the backward fed by them."""
+    round 4 - 64-key tiles otherwise) and, for fp16 from 2^24 (query, key) pairs (2^26 under a mask), to the 16x16x32 kernel with 128-key tiles
+    (fa_fwd_pp16.hip): both sides of every switch, ragged tails and sq != sk, forward values and LSE against fp32 math, and the backward fed by them."""
     import flash_attn_turing as F
 
     gen = torch.Generator(device="cpu").manual_seed(sq * 7 + sk)

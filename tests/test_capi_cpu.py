@@ -3,6 +3,7 @@ validation works without a GPU (no compute calls here)."""
 import ctypes
 
 import pytest
+import torch
 
 from flash_attn_turing import capi
 
@@ -23,12 +24,21 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.fwd_kernel_name(128) == "fa_fwd_pp_kernel"
     assert capi.lib().fa_set_kernel_policy(3) == -1 and capi.lib().fa_set_kernel_policy(-1) == -1
     assert capi.set_kernel_policy(capi.POLICY_AUTO) == capi.POLICY_MFMA32
-    assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel" and capi.fwd_kernel_name(64) == "fa_fwd_pp_kernel"
+    assert capi.fwd_kernel_name(128) == "fa_fwd_pp16_kernel" and capi.fwd_kernel_name(64) == "fa_fwd_pp16_kernel"      # (64: fp16, round 4)
     # fa_kernel_name: the default policy's choices at the BASELINE shapes and at small ones
     assert capi.kernel_name("fwd", 4, 16384, 16384, 32, 128, True) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 128, False) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 1, 512, 512, 4, 128, False) == "fa_fwd_pp_kernel"
-    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False) == "fa_fwd_pp_kernel"
+    # head_dim 64 (round 4): fp16 from 2^24 pairs per head (2^26 under a causal mask) on the 16x16x32 forward, bf16 never unless pinned
+    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False) == "fa_fwd_pp16_kernel"
+    assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 64, False) == "fa_fwd_pp16_kernel"
+    assert capi.kernel_name("fwd", 4, 2048, 2048, 32, 64, False) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 64, True) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, True) == "fa_fwd_pp16_kernel"
+    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False, "bf16") == capi.kernel_name("fwd", 4, 16384, 16384, 32, 64, True, "bf16") == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 128, False, "bf16") == "fa_fwd_pp16_kernel"
+    assert capi.lib().fa_kernel_name(0, 4, 8192, 8192, 32, 64, 0) == capi.lib().fa_kernel_name_dtype(0, 0, 4, 8192, 8192, 32, 64, 0)      # fa_kernel_name = fp16
+    assert capi.lib().fa_kernel_name_dtype(0, 7, 4, 8192, 8192, 32, 64, 0) == b""
     assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dq16_kernel"
     assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, True) == "fa_bwd_dq_kernel"
     assert capi.kernel_name("dq", 4, 16384, 16384, 32, 128, True) == "fa_bwd_dq16_kernel"       # round 4: causal dQ from 2^28 pairs per head
@@ -49,7 +59,12 @@ def test_package_level_policy_helpers():
 
     assert F.set_kernel_policy("mfma16") == "auto"
     assert F.kernel_name("fwd", 1, 128, 128, 1, 128, False) == "fa_fwd_pp16_kernel"
+    assert F.kernel_name("fwd", 1, 128, 128, 1, 64, False, torch.bfloat16) == "fa_fwd_pp16_kernel"      # pinned: both dtypes
     assert F.set_kernel_policy("auto") == "mfma16"
+    assert F.kernel_name("fwd", 1, 8192, 8192, 1, 64, False, torch.bfloat16) == "fa_fwd_pp_kernel"
+    assert F.kernel_name("fwd", 1, 8192, 8192, 1, 64, False, torch.float16) == F.kernel_name("fwd", 1, 8192, 8192, 1, 64, False) == "fa_fwd_pp16_kernel"
+    with pytest.raises(ValueError):
+        F.kernel_name("fwd", 1, 8192, 8192, 1, 64, False, torch.float32)
     assert F.kernel_name("fwd", 1, 128, 128, 1, 128, False) == "fa_fwd_pp_kernel"
     with pytest.raises(ValueError):
         F.set_kernel_policy("fastest")

@@ -97,13 +97,14 @@ def test_mfma16_forward_keeps_its_accumulators_in_place(kernels):
             main = max(info["loops"], key=lambda l: l["mfma"])
             # three tiles of 64; the fp16 instances sum their softmax rows in the matrix pipe (round 4: +4 ones-row MFMAs per tile, and the
             # row-sum adds must be gone from the loop - only the ~6 address / bookkeeping adds remain)
-            rowsum = "IDF16_" in name
-            assert main["mfma"] == (204 if rowsum else 192), (name, main["mfma"])
+            # head_dim 64 (128-key tiles, round 4): the same 64 MFMAs per tile, +8 ones-row MFMAs (four 32-key chunks)
+            rowsum, d64 = "IDF16_" in name, "Li64ELb" in name
+            assert main["mfma"] == ((216 if d64 else 204) if rowsum else 192), (name, main["mfma"])
             if rowsum:
-                assert main["histogram"].get("v_add_f32_e32", 0) <= 12 and main["histogram"].get("v_pk_maximum3_f16", 0) == 24, (name, main["histogram"])
+                assert main["histogram"].get("v_add_f32_e32", 0) <= 12 and main["histogram"].get("v_pk_maximum3_f16", 0) == (48 if d64 else 24), (name, main["histogram"])
             assert main["histogram"].get("v_mov_b64_e32", 0) == 0, (name, main["histogram"])
             assert main["histogram"].get("v_mov_b32_e32", 0) <= 24, (name, main["histogram"])
-    assert seen == 4
+    assert seen == 8
 
 
 def test_dkdv16_ring_addresses_are_toggled_not_recomputed(kernels):

@@ -33,31 +33,50 @@ def pinned_set(gpu, request):
     capi.set_kernel_policy(prev)
 
 
-def _d128_golden():
-    return [n for n in U.golden_names() if U.load_golden(n)["q"].shape[-1] == 128]
+def _d64_only_once(d, pinned_set):
+    """head_dim 64 has one kernel set except for its forward, which since round 4 also exists in the 16x16x32 tiling (fp16 large problems under
+    the default policy, everything when that set is pinned): the pinned-16x16x32 pass is the new coverage, the pinned-32x32x16 pass would repeat
+    what the other modules already run"""
+    if d == 64 and pinned_set != "mfma16":
+        pytest.skip("head_dim 64 under the 32x32x16 pin is what the default suite runs")
 
 
-@pytest.mark.parametrize("name", _d128_golden())
+def _golden(d):
+    return [n for n in U.golden_names() if U.load_golden(n)["q"].shape[-1] == d]
+
+
+@pytest.mark.parametrize("name", _golden(128))
 def test_golden_vectors(gpu, name):
     TA.test_golden_vectors(gpu, name)
 
 
-@pytest.mark.parametrize("b,sq,sk,h,hk,d,causal,dtype", [c for c in TA.ORACLE_CASES if c[5] == 128])
-def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype):
+@pytest.mark.parametrize("name", _golden(64))
+def test_golden_vectors_head_dim_64(gpu, name, pinned_set):
+    _d64_only_once(64, pinned_set)
+    TA.test_golden_vectors(gpu, name)
+
+
+@pytest.mark.parametrize("b,sq,sk,h,hk,d,causal,dtype", TA.ORACLE_CASES)
+def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype, pinned_set):
+    _d64_only_once(d, pinned_set)
     TA.test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype)
 
 
 @pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [128, 64])
 @pytest.mark.parametrize("batch_size", [1, 3])
 @pytest.mark.parametrize("nheads,nheads_k", [(2, 1), (6, 3), (6, 1), (4, 4)])
-def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, causal):
-    TA.test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, 128, causal)
+def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, causal, pinned_set):
+    _d64_only_once(d, pinned_set)
+    TA.test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, causal)
 
 
 @pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [128, 64])
 @pytest.mark.parametrize("nheads,nheads_k", [(4, 2), (6, 1), (2, 2)])
-def test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, causal):
-    TA.test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, 128, causal)
+def test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, d, causal, pinned_set):
+    _d64_only_once(d, pinned_set)
+    TA.test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, d, causal)
 
 
 def test_online_softmax_rescale_spike(gpu):
@@ -85,14 +104,18 @@ def test_nonfinite_scores_propagate_like_fp32_math(gpu):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-def test_identity_inputs_analytic_known_answer(gpu, causal):
-    TP.test_identity_inputs_analytic_known_answer(gpu, 128, causal)
+@pytest.mark.parametrize("d", [128, 64])
+def test_identity_inputs_analytic_known_answer(gpu, d, causal, pinned_set):
+    _d64_only_once(d, pinned_set)
+    TP.test_identity_inputs_analytic_known_answer(gpu, d, causal)
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("d", [128, 64])
 @pytest.mark.parametrize("ramp", [1.0, 0.02, -1.0])
-def test_running_max_rising_along_the_key_axis(gpu, dtype, ramp):
-    TP.test_running_max_rising_along_the_key_axis(gpu, 128, dtype, ramp)
+def test_running_max_rising_along_the_key_axis(gpu, d, dtype, ramp, pinned_set):
+    _d64_only_once(d, pinned_set)
+    TP.test_running_max_rising_along_the_key_axis(gpu, d, dtype, ramp)
 
 
 def test_launch_path_is_hip_graph_capturable(gpu):

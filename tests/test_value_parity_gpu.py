@@ -28,6 +28,9 @@ FWD_CASES = {
     "c2_fwd_4k": (4, 4096, 32, 128, False, "fp16"),            # BASELINE configs[1]
     "c3_fwd_16k_causal": (4, 16384, 32, 128, True, "fp16"),    # BASELINE configs[2] (the headline)
     "c5shard_fwd_16k": (4, 16384, 32, 128, False, "fp16"),     # one GPU's share of BASELINE configs[4]
+    # head_dim 64 at the sizes the default policy hands to the 16x16x32 forward (fp16, round 4; reference README.md:12-18 quotes hdim 64 too)
+    "d64_fwd_8k_fp16": (2, 8192, 8, 64, False, "fp16"),
+    "d64_fwd_8k_causal_fp16": (2, 8192, 8, 64, True, "fp16"),
 }
 BWD_CASES = {
     "c4_fwdbwd_8k_bf16": (4, 8192, 32, 128, False, "bf16"),    # BASELINE configs[3]

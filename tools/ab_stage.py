@@ -38,6 +38,10 @@ CONFIGS = {
     "fp16 d64 2k causal": (4, 2048, 32, 32, 64, F16, True),
     "fp16 d128 512 causal": (4, 512, 32, 32, 128, F16, True),
     "fp16 d64 8k": (4, 8192, 32, 32, 64, F16, False),
+    "fp16 d64 2k": (4, 2048, 32, 32, 64, F16, False),
+    "fp16 d64 4k": (4, 4096, 32, 32, 64, F16, False),
+    "fp16 d64 16k": (4, 16384, 32, 32, 64, F16, False),
+    "bf16 d64 8k": (4, 8192, 32, 32, 64, BF16, False),
     "fp16 d64 8k causal": (4, 8192, 32, 32, 64, F16, True),
     "bf16 d128 8k mqa causal": (4, 8192, 32, 1, 128, BF16, True),
     "fp16 d128 gqa 4k causal": (4, 4096, 32, 8, 128, F16, True),
