@@ -8,22 +8,24 @@ sys.path.insert(0, os.path.join(ROOT, "flash-attention-turing_amd"))
 from flash_attn_turing import capi
 ap = argparse.ArgumentParser()
 ap.add_argument("--b", type=int, default=4); ap.add_argument("--h", type=int, default=32); ap.add_argument("--dtype", default="fp16")
-ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--seqs", default="1024,2048,4096,8192,16384")
+ap.add_argument("--d", type=int, default=128); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--seqs", default="1024,2048,4096,8192,16384")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
 for causal in (False, True):
     for s in (int(x) for x in a.seqs.split(",")):
         g = torch.Generator(device=dev).manual_seed(s)
-        q, k, v, do = (torch.randn(a.b, s, a.h, 128, device=dev, dtype=dt, generator=g) for _ in range(4))
+        q, k, v, do = (torch.randn(a.b, s, a.h, a.d, device=dev, dtype=dt, generator=g) for _ in range(4))
         o, dq, dk, dv = (torch.empty_like(q) for _ in range(4)); lse, dsum = (torch.empty(a.b, a.h, s, device=dev, dtype=torch.float32) for _ in range(2))
         pb = capi.bwd_params(q, k, v, o, lse, do, dq, dk, dv, dsum, causal)
         capi.set_kernel_policy(capi.POLICY_AUTO)
         capi.mha_fwd(q, k, v, o, lse, causal); capi.bwd_stage("dq", pb); torch.cuda.synchronize()
-        auto = {st: capi.kernel_name(st, a.b, s, s, a.h, 128, causal) for st in ("fwd", "dq", "dkdv")}
-        iters = 10 if s <= 4096 else 3
+        auto = {st: capi.kernel_name(st, a.b, s, s, a.h, a.d, causal, a.dtype) for st in ("fwd", "dq", "dkdv")}
         row = []
-        for st in ("fwd", "dq", "dkdv"):
+        for st in (("fwd", "dq", "dkdv") if a.d == 128 else ("fwd",)):          # head_dim 64 has one backward set
             f = (lambda: capi.mha_fwd(q, k, v, o, lse, causal)) if st == "fwd" else (lambda: capi.bwd_stage(st, pb))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); f(); f(); e1.record(); e1.synchronize()
+            iters = max(3, min(200, int(10.0 / max(e0.elapsed_time(e1) / 3, 1e-3))))      # windows of ~10 ms
             t = {0: [], 1: []}
             for _ in range(a.rounds):
                 for pol in (0, 1):
