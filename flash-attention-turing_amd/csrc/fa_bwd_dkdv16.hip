@@ -28,6 +28,12 @@ namespace fa {
 #define FA_KV16_PF 4          // transposed fragments in flight in the dV / dK phase (3: one spill op per tile in the causal instances; 2-4 time the same)
 #endif
 
+#ifndef FA_KV16_DMA_EARLY
+#define FA_KV16_DMA_EARLY 0   // which q-half group requests the next tile at the top of the loop (the other one after its S / dP MFMAs); 2 = both at the top
+#endif
+#ifndef FA_KV16_ABL
+#define FA_KV16_ABL 0         // timing-only ablations (results are WRONG), bit mask: 1 no workgroup barrier at the end of a tile, 2 no row-fragment LDS reads in the
+#endif                        // S / dP phase, 8 no exponentials, 16 no LDS-DMA of the next tile, 32 the DMA is not waited for (profiles/r4_bwd_dkdv16_ablations.log)
 #ifndef FA_KV16_NOP_ONCE
 #define FA_KV16_NOP_ONCE 1    // the VALU -> MFMA source hazard of the asm-issued dV / dK MFMAs (P / dS come straight from v_cvt_pk) is padded once, in
 #endif                        // front of the phase, instead of with an s_nop in front of each of its 32 MFMAs: -0.2..-0.8 %
@@ -247,8 +253,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
         FA_LDS char* sbuf = stat + buf * STATB;
 #endif
         const bool more = (it + 1 < n_iters);
-        if (more && qh == 0) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
-        const float st_next = load_stat(more);
+#if !(FA_KV16_ABL & 16)
+        if (more && (FA_KV16_DMA_EARLY == 2 || qh == FA_KV16_DMA_EARLY)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
+#endif
+        const float st_next = load_stat(more);          // (every wave, six of the eight against an empty range: guarding it by `wave < 2` cost the non-causal instances 8-12 %)
 
         const int mh = m0 + 32 * qh;                       // first query row of this wave's half
         // (no wave-level causal skip, on purpose: fa_bwd.hip.  A fully masked wave-tile runs the body with P = dS = 0 by select.)
@@ -273,7 +281,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
                 u32x4 qa[2], da[2], vf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-#if FA_KV16_TOGGLE
+#if FA_KV16_ABL & 2
+                    qa[i] = kreg[ks][i]; da[i] = kreg[ks][i ^ 1];
+#elif FA_KV16_TOGGLE
                     qa[i] = lds_read16(at(rq[ks]), 16 * i * ROWB);
                     da[i] = lds_read16(at(rq[ks]), 2 * TILEB + 16 * i * ROWB);
 #else
@@ -283,7 +293,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
                 }
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc)
-#if FA_KV16_TOGGLE && FA_KV16_RV
+#if FA_KV16_ABL & 2
+                    vf[kc] = ks < VREG ? vreg[ks < VREG ? ks : 0][kc] : kreg[ks][kc ^ 1];
+#elif FA_KV16_TOGGLE && FA_KV16_RV
                     vf[kc] = ks < VREG ? vreg[ks < VREG ? ks : 0][kc] : lds_read16(at(rv[ks]), 16 * kc * ROWB);
 #else
                     vf[kc] = ks < VREG ? vreg[ks < VREG ? ks : 0][kc] : lds_read16(vtile, row_rd[ks] + (kb * 32 + 16 * kc) * ROWB);
@@ -296,7 +308,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
                         dpacc[i][kc] = LP<T>::mfma16(da[i], vf[kc], ks == 0 ? nd4[i] : dpacc[i][kc]);                              // dP - D = dO V^T - D
                     }
             }
-            if (more && qh == 1) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
+#if !(FA_KV16_ABL & 16)
+            if (more && FA_KV16_DMA_EARLY != 2 && qh == (FA_KV16_DMA_EARLY ^ 1)) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
+#endif
             if (more) pf_advance();
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -310,7 +324,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
+#if FA_KV16_ABL & 8
+                    for (int r = 0; r < 4; ++r) sacc[i][kc][r] = sacc[i][kc][r];
+#else
                     for (int r = 0; r < 4; ++r) sacc[i][kc][r] = fast_exp2(__builtin_fmaf(sacc[i][kc][r], c, nl4[i][r]));      // P (flash_bwd_kernel.h:1329)
+#endif
             if (need_mask) {                                        // wave-uniform branch: only diagonal tiles pay for the select
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -367,7 +385,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
         }
         if (more && wave < 2) store_stat(st_next, buf ^ 1);
         asm volatile("" :: "v"(st_next));               // consumed on every path: hipcc never has to guard the register at the loop top
+#if !(FA_KV16_ABL & 32)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
+#endif
 #if FA_KV16_TOGGLE
         // on to the other ring slot (inline asm: hipcc would otherwise re-derive the addresses from `buf` and put the adds back)
 #pragma unroll
@@ -376,7 +396,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
         for (int db = 0; db < DB; ++db) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(rt[db]) : "s"((uint32_t)TILEB));
         asm volatile("v_xor_b32 %0, %1, %0" : "+v"(rs) : "s"((uint32_t)STATB));
 #endif
+#if !(FA_KV16_ABL & 1)
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: the loop's last barrier has passed, K / V tiles, rings and stats are dead, LDS is scratch (fa_bwd_dkdv_common.hpp

@@ -22,6 +22,8 @@ SHAPES = [  # b, sq, sk, h, hk, d, dtype, causal
     (64, 512, 512, 8, 8, 128, torch.float16, True),         # many short workgroups
     (1, 16384, 16384, 8, 8, 128, torch.float16, True),      # the headline's per-head problem (the 16x16x32 forward under every policy but mfma32)
     (2, 300, 4100, 4, 2, 128, torch.bfloat16, False),       # few rows, long ragged key axis
+    (2, 4096, 4096, 16, 16, 64, torch.float16, False),      # head_dim 64 on the 16x16x32 forward under the default policy (round 4)
+    (1, 8192, 8300, 8, 4, 64, torch.float16, True),         # the same under a mask, ragged key axis
 ]
 
 
