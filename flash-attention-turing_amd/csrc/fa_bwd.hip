@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
     auto dma_tiles = [&](int t, int buf) {                 // K(t), V(t) -> LDS buffers `buf`
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
-            dma16_to_lds_hidden(k_srd, (uint32_t)(t * kDqBlockN) * k_rowb + dma_goff_k[i], lds_k0 + buf * TILEB + i * 1024);
-            dma16_to_lds_hidden(v_srd, (uint32_t)(t * kDqBlockN) * v_rowb + dma_goff_v[i], lds_v0 + buf * TILEB + i * 1024);
+            dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(k_srd, (uint32_t)(t * kDqBlockN) * k_rowb + dma_goff_k[i], lds_k0 + buf * TILEB + i * 1024);
+            dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(v_srd, (uint32_t)(t * kDqBlockN) * v_rowb + dma_goff_v[i], lds_v0 + buf * TILEB + i * 1024);
         }
     };
     uint32_t row_rd[KS];       // row reads of K (for S^T) and V (for dP^T): same (row, slot) pattern
@@ -528,8 +528,8 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
             for (int i = 0; i < PPW_Q; ++i) {
                 const int piece = wave * PPW_Q + i;
-                dma16_to_lds_hidden(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
-                dma16_to_lds_hidden(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
+                dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
+                dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
             }
     };
     // Statistics of the tile at the cursor: loaded when the tile's DMA is issued, transformed (-LSE*log2e, -D) and written to the stats
@@ -552,8 +552,8 @@ __global__ __launch_bounds__(kKvThreads, FA_KV_MIN_WAVES(D)) void fa_bwd_dkdv_ke
 #pragma unroll
     for (int i = 0; i < PPW_KV; ++i) {
         const int piece = wave * PPW_KV + i;
-        dma16_to_lds_hidden(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
-        dma16_to_lds_hidden(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
+        dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
+        dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
     }
     if (n_iters > 0) {
         set_head(pf_head);

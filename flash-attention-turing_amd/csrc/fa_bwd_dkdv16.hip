@@ -185,8 +185,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 #pragma unroll
         for (int i = 0; i < PPW_Q; ++i) {
             const int piece = wave * PPW_Q + i;
-            dma16_to_lds_hidden(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
-            dma16_to_lds_hidden(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
+            dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
+            dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
         }
     };
     const float st_mult = wave == 0 ? -kLog2e : -1.0f;
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 #pragma unroll
     for (int i = 0; i < PPW_KV; ++i) {
         const int piece = wave * PPW_KV + i;
-        dma16_to_lds_hidden(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
-        dma16_to_lds_hidden(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
+        dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(k_srd, piece_src(piece, k_rowb), lds0 + piece * 1024);
+        dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(v_srd, piece_src(piece, v_rowb), lds0 + OFF_V + piece * 1024);
     }
     if (n_iters > 0) {
         set_head(pf_head);

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
     auto dma_tiles = [&](int t, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
-            dma16_to_lds_hidden(k_srd, (uint32_t)(t * kDq16BlockN) * k_rowb + dma_goff_k[i], lds_k0 + buf * TILEB + i * 1024);
-            dma16_to_lds_hidden(v_srd, (uint32_t)(t * kDq16BlockN) * v_rowb + dma_goff_v[i], lds_v0 + buf * TILEB + i * 1024);
+            dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(k_srd, (uint32_t)(t * kDq16BlockN) * k_rowb + dma_goff_k[i], lds_k0 + buf * TILEB + i * 1024);
+            dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(v_srd, (uint32_t)(t * kDq16BlockN) * v_rowb + dma_goff_v[i], lds_v0 + buf * TILEB + i * 1024);
         }
     };
     // row reads of K (A of S^T = K Q^T) and V (A of dP^T = V dO^T): key block kb, k-step ks -> row 16*kb + 4*kPi2[i >> 2] + (i & 3) for

@@ -72,6 +72,11 @@ struct BwdKernelParams {
 // its K / V stays in the XCD's L2).  `tiles` / `rows` are those of the axis the grid walks (query tiles; key blocks for dK/dV), `wg_per_cu` the
 // workgroups of this kernel a compute unit holds at a time (2 for the narrow head_dim-64 kernels); an XCD has 32 compute units.
 // FA_CAUSAL_ORDER 0 = one head after the other everywhere (A/B).  profiles/r4_causal_tile_order_ab.log, r4_causal_tile_order_long_ab.log, r4_causal_group_order_ab.log
+#ifndef FA_BWD_DMA_SAVE_M0
+#define FA_BWD_DMA_SAVE_M0 0  // backward kernels: 1 = save / restore M0 around every hand-issued LDS-DMA piece (fa_device.hpp:dma16_to_lds_hidden).  Like the forward
+                              // kernels they hold no compiler-visible LDS-DMA and nothing hipcc generates for them touches M0 (tests/test_kernel_resources_cpu.py keeps
+                              // that true), so the two SALU per piece are dropped: -0.1..-1.4 %, bit-identical (profiles/r4_bwd_dma_no_m0_save_ab.log)
+#endif
 #ifndef FA_CAUSAL_ORDER
 #define FA_CAUSAL_ORDER 1
 #endif

@@ -74,15 +74,19 @@ def test_d64_kernels_fit_two_workgroups_per_cu(kernels):
     assert len(wide) == 4, wide                                                                      # <T, 64, CAUSAL, BN = 128>
 
 
-def test_forward_kernels_touch_m0_only_in_their_own_lds_dma_statements(kernels):
-    """fa_fwd_pp issues every LDS-DMA from inline asm WITHOUT saving / restoring M0 (dma16_to_lds_hidden<false>); that is only sound while
-    nothing hipcc generates for those kernels reads or writes M0 (no compiler-visible LDS-DMA, no indirect register indexing)"""
-    seen = 0
+def test_kernels_touch_m0_only_in_their_own_lds_dma_statements(kernels):
+    """every kernel issues its LDS-DMA from inline asm WITHOUT saving / restoring M0 (dma16_to_lds_hidden<false>; the backward ones since
+    round 4, FA_BWD_DMA_SAVE_M0 = 0); that is only sound while nothing hipcc generates for those kernels reads or writes M0 (no
+    compiler-visible LDS-DMA, no indirect register indexing)"""
+    fwd = bwd = 0
     for (f, name), info in kernels.items():
         if "fa_fwd_pp_kernel" in name or "fa_fwd_pp16_kernel" in name:
-            seen += 1
+            fwd += 1
             assert info["m0_outside_asm"] == 0, (name, info["m0_outside_asm"])
-    assert seen >= 12
+        if any(k in name for k in ("fa_bwd_dq_kernel", "fa_bwd_dq16_kernel", "fa_bwd_dkdv_kernel", "fa_bwd_dkdv16_kernel")):
+            bwd += 1
+            assert info["m0_outside_asm"] == 0, (name, info["m0_outside_asm"])
+    assert fwd >= 16 and bwd >= 24, (fwd, bwd)
 
 
 def test_mfma16_forward_keeps_its_accumulators_in_place(kernels):
