@@ -56,6 +56,9 @@ constexpr float kPpDeferLog2 = 6.0f;
 #ifndef FA_PP16_EXACT_TILES
 #define FA_PP16_EXACT_TILES 16
 #endif
+#ifndef FA_PP16_ABL
+#define FA_PP16_ABL 0       // timing-only ablations (results may be WRONG): 1 = the steady loop does not wait for its LDS-DMA
+#endif
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
@@ -542,7 +545,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             dma_role_tile(uu + 2, S_UM1);
             softmax_step(uu, no{}, no{}, mlc);
             m_prefetch(S_U, S_UP1);
+#if !(FA_PP16_ABL & 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
+#endif
             __syncthreads();
 #else
             if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
