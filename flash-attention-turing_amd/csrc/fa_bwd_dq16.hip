@@ -20,6 +20,9 @@ namespace fa {
 constexpr int kDq16Threads = 512;
 constexpr int kDq16BlockM = 256;
 constexpr int kDq16BlockN = 64;
+#ifndef FA_DQ16_ABL
+#define FA_DQ16_ABL 0         // timing-only ablations (results may be WRONG): 1 = the LDS-DMA of the next tile is not waited for
+#endif
 #ifndef FA_DQ16_STAGGER_DMA
 #define FA_DQ16_STAGGER_DMA 1
 #endif
@@ -231,7 +234,9 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
                 }
             }
         }
+#if !(FA_DQ16_ABL & 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t+1 have landed
+#endif
     };
     {
         int t = 0;
