@@ -33,7 +33,7 @@ namespace fa {
 #endif
 #ifndef FA_KV16_ABL
 #define FA_KV16_ABL 0         // timing-only ablations (results are WRONG), bit mask: 1 no workgroup barrier at the end of a tile, 2 no row-fragment LDS reads in the
-#endif                        // S / dP phase, 8 no exponentials, 16 no LDS-DMA of the next tile, 32 the DMA is not waited for (profiles/r4_bwd_dkdv16_ablations.log)
+#endif                        // S / dP phase, 8 no exponentials, 16 no LDS-DMA of the next tile, 32 nothing of the next tile is waited for (no vmcnt wait in the loop at all; the statistics are not refreshed) (profiles/r4_bwd_dkdv16_ablations.log)
 #ifndef FA_KV16_NOP_ONCE
 #define FA_KV16_NOP_ONCE 1    // the VALU -> MFMA source hazard of the asm-issued dV / dK MFMAs (P / dS come straight from v_cvt_pk) is padded once, in
 #endif                        // front of the phase, instead of with an s_nop in front of each of its 32 MFMAs: -0.2..-0.8 %
@@ -383,8 +383,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if !(FA_KV16_ABL & 32)
         if (more && wave < 2) store_stat(st_next, buf ^ 1);
         asm volatile("" :: "v"(st_next));               // consumed on every path: hipcc never has to guard the register at the loop top
+#endif
 #if !(FA_KV16_ABL & 32)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
 #endif
