@@ -31,6 +31,9 @@ namespace fa {
 #ifndef FA_KV16_DMA_EARLY
 #define FA_KV16_DMA_EARLY 0   // which q-half group requests the next tile at the top of the loop (the other one after its S / dP MFMAs); 2 = both at the top
 #endif
+#ifndef FA_KV16_STAT_PRED
+#define FA_KV16_STAT_PRED(CAUSAL) (!(CAUSAL))   // the per-tile statistics load under an EXEC mask in the six waves that do not use it: the non-causal instances only
+#endif
 #ifndef FA_KV16_ABL
 #define FA_KV16_ABL 0         // timing-only ablations (results are WRONG), bit mask: 1 no workgroup barrier at the end of a tile, 2 no row-fragment LDS reads in the
 #endif                        // S / dP phase, 8 no exponentials, 16 no LDS-DMA of the next tile, 32 nothing of the next tile is waited for (no vmcnt wait in the loop at all; the statistics are not refreshed) (profiles/r4_bwd_dkdv16_ablations.log)
@@ -256,7 +259,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 #if !(FA_KV16_ABL & 16)
         if (more && (FA_KV16_DMA_EARLY == 2 || qh == FA_KV16_DMA_EARLY)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
 #endif
-        const float st_next = load_stat(more);          // (every wave, six of the eight against an empty range: guarding it by `wave < 2` cost the non-causal instances 8-12 %)
+        // Only the two statistics waves need this load, and a vector-memory instruction costs its wave ~100 cycles whatever it returns.  A LANE-dependent condition
+        // (an EXEC mask around the instruction) in the non-causal instances: -0.6..-1.2 %; under a mask 0..+1.3 %, so those keep the load in all eight waves; the
+        // wave-uniform `wave < 2` (a scalar branch) cost the non-causal instances 8-12 % (profiles/r4_bwd_dkdv16_ablations.log 6, 7)
+        float st_next = 0.f;
+        if (!FA_KV16_STAT_PRED(CAUSAL) || tid < 128) st_next = load_stat(more);
 
         const int mh = m0 + 32 * qh;                       // first query row of this wave's half
         // (no wave-level causal skip, on purpose: fa_bwd.hip.  A fully masked wave-tile runs the body with P = dS = 0 by select.)
