@@ -771,9 +771,13 @@ def main():
                 capi.set_kernel_policy(capi.POLICY_AUTO)
             m32, m16, mauto = (_st.median(times[pol]) for pol in (capi.POLICY_MFMA32, capi.POLICY_MFMA16, capi.POLICY_AUTO))
             stages = ("dq", "dkdv") if bw else ("fwd",)
+            picks = {st_: capi.kernel_name(st_, bb, ss, ss, hh, 128, cz, dt_) for st_ in stages}
             ab[label] = {"ms_mfma_32x32x16": m32, "ms_mfma_16x16x32": m16, "ms_auto": mauto, "ratio_16_over_32": m16 / m32,
-                         "ratio_auto_over_best_pinned": mauto / min(m32, m16),
-                         "auto_picks": {st_: capi.kernel_name(st_, bb, ss, ss, hh, 128, cz) for st_ in stages}}
+                         "ratio_auto_over_best_pinned": mauto / min(m32, m16), "auto_picks": picks}
+            # when AUTO launches exactly the kernels of one pinned set, the two arms time the SAME code: their ratio is this measurement's noise floor
+            same = "mfma16" if all("16_kernel" in k_ for k_ in picks.values()) else "mfma32" if not any("16_kernel" in k_ for k_ in picks.values()) else None
+            if same is not None:
+                ab[label].update({"auto_launches_the_kernels_of": same, "noise_floor_same_kernels_ratio": mauto / (m16 if same == "mfma16" else m32)})
             del et
             torch.cuda.empty_cache()
         extra["kernel_sets_ab"] = ab

@@ -57,8 +57,8 @@ constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PP16_EXACT_TILES 16
 #endif
 #ifndef FA_PP16_ABL
-#define FA_PP16_ABL 0       // timing-only ablations (results may be WRONG): 1 = the steady loop does not wait for its LDS-DMA
-#endif
+#define FA_PP16_ABL 0       // timing-only ablations (results WRONG), bit mask: 1 the steady loop does not wait for its LDS-DMA, 2 does not issue it, 4 no exponentials (one multiply
+#endif                      // per score instead of fma + exp), 8 no LDS fragment reads in the matrix phases (profiles/r4_fwd_pp16_ablations.log)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
@@ -238,6 +238,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     // so LDS bytes per FLOP are those of the 32x32x16 kernel.  Fragment j + PF is requested before the MFMAs of fragment j.
     constexpr int NPV = NC * DB, NQK = NKB * KS, NST = NPV + NQK, PF = FA_PP16_PF;
     auto m_frag = [&](int j, int slot_v, int slot_k) __attribute__((always_inline)) -> u32x4 {
+#if FA_PP16_ABL & 8
+        return qf[j % KS][(j >> 2) & 1];
+#endif
         if (j < NPV) {
             const int db = j % DB, cch = j / DB;
             const u32x2 a0 = lds_read_tr8((const FA_LDS char*)(uintptr_t)v_rd[db], slot_v * TILEB + (32 * cch) * ROWB);
@@ -368,8 +371,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 ps[qb] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
+#if FA_PP16_ABL & 4
+                    const float p0 = sacc[kb][qb][0] * 0.01f + mc0 * 0.f, p1 = sacc[kb][qb][1] * 0.01f, p2 = sacc[kb][qb][2] * 0.01f, p3 = sacc[kb][qb][3] * 0.01f;
+#else
                     const float p0 = fast_exp2(__builtin_fmaf(sacc[kb][qb][0], c, -mc0)), p1 = fast_exp2(__builtin_fmaf(sacc[kb][qb][1], c, -mc0));
                     const float p2 = fast_exp2(__builtin_fmaf(sacc[kb][qb][2], c, -mc0)), p3 = fast_exp2(__builtin_fmaf(sacc[kb][qb][3], c, -mc0));
+#endif
                     if constexpr (!MLT) { ps[qb] += p0; ps[qb] += p1; ps[qb] += p2; ps[qb] += p3; }
                     if (kb & 1) { pf[kb >> 1][qb].z = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].w = LP<T>::pack2(p2, p3); }
                     else { pf[kb >> 1][qb].x = LP<T>::pack2(p0, p1); pf[kb >> 1][qb].y = LP<T>::pack2(p2, p3); }
@@ -542,10 +549,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             // group A: K(u+2) -> the slot K(u-1) left (last read in M(u-1), which group B finished one barrier ago);
             // group B: V(u+2) -> the slot V(u-1) left (last read in M(u), which group B itself has just finished and group A one phase earlier).
             // Retired: the tile requested one softmax phase ago (K(u+1) / V(u+1)), by count - this phase's four pieces stay in flight.
+#if !(FA_PP16_ABL & 2)
             dma_role_tile(uu + 2, S_UM1);
+#endif
             softmax_step(uu, no{}, no{}, mlc);
             m_prefetch(S_U, S_UP1);
-#if !(FA_PP16_ABL & 1)
+#if !(FA_PP16_ABL & 3)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
 #endif
             __syncthreads();
