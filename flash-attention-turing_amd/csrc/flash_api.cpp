@@ -261,12 +261,58 @@ std::vector<at::Tensor> mha_varlen_bwd(at::Tensor q, at::Tensor k, at::Tensor v,
     return {dq, dk, dv};
 }
 
+// ---- autograd nodes in C++ ------------------------------------------------------------------------------------------------------
+// The reference ships the four raw functions only; its README's flash_attn_func is an older Python-level API.  The differentiable wrappers
+// of this package used to be torch.autograd.Function subclasses in Python: ~85 us of host time per forward + backward, more than the GPU
+// work of a b1 x 512-token call (58 us).  As C++ nodes the same pair costs the host 42-52 us (tools/host_overhead.py, profiles/r4_host_overhead.log).
+class FlashAttnNode : public torch::autograd::Function<FlashAttnNode> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor q, at::Tensor k, at::Tensor v, bool is_causal) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        std::vector<at::Tensor> r = mha_fwd(q, k, v, is_causal);
+        ctx->save_for_backward({q, k, v, r[0], r[1]});
+        ctx->saved_data["causal"] = is_causal;
+        return r[0];
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list grads) {
+        const torch::autograd::variable_list s = ctx->get_saved_variables();
+        std::vector<at::Tensor> g = mha_bwd(s[0], s[1], s[2], s[3], s[4], grads[0], ctx->saved_data["causal"].toBool());      // strided dout is fine
+        return {g[0], g[1], g[2], at::Tensor()};
+    }
+};
+class FlashAttnVarlenNode : public torch::autograd::Function<FlashAttnVarlenNode> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor cu_seqlens_q, at::Tensor cu_seqlens_k,
+                              int64_t max_seqlen_q, int64_t max_seqlen_k, bool is_causal) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        std::vector<at::Tensor> r = mha_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, (int)max_seqlen_q, (int)max_seqlen_k, is_causal);
+        ctx->save_for_backward({q, k, v, r[0], r[1], cu_seqlens_q, cu_seqlens_k});
+        ctx->saved_data["causal"] = is_causal;
+        ctx->saved_data["max_q"] = max_seqlen_q;
+        ctx->saved_data["max_k"] = max_seqlen_k;
+        return r[0];
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list grads) {
+        const torch::autograd::variable_list s = ctx->get_saved_variables();
+        std::vector<at::Tensor> g = mha_varlen_bwd(s[0], s[1], s[2], s[3], s[4], grads[0], s[5], s[6], (int)ctx->saved_data["max_q"].toInt(),
+                                                   (int)ctx->saved_data["max_k"].toInt(), ctx->saved_data["causal"].toBool());
+        return {g[0], g[1], g[2], at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+static at::Tensor attn_autograd(at::Tensor q, at::Tensor k, at::Tensor v, bool is_causal) { return FlashAttnNode::apply(q, k, v, is_causal); }
+static at::Tensor attn_varlen_autograd(at::Tensor q, at::Tensor k, at::Tensor v, at::Tensor cu_seqlens_q, at::Tensor cu_seqlens_k, int64_t max_seqlen_q,
+                                       int64_t max_seqlen_k, bool is_causal) {
+    return FlashAttnVarlenNode::apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "MI355X (gfx950) fused attention behind the flash_attn_turing surface";
     m.def("fwd", &mha_fwd, "Forward pass");
     m.def("bwd", &mha_bwd, "Backward pass");
     m.def("varlen_fwd", &mha_varlen_fwd, "Varlen forward pass");
     m.def("varlen_bwd", &mha_varlen_bwd, "Varlen backward pass");
+    m.def("attn_autograd", &attn_autograd, "differentiable forward (C++ autograd node over fwd / bwd)");
+    m.def("attn_varlen_autograd", &attn_varlen_autograd, "differentiable packed forward (C++ autograd node over varlen_fwd / varlen_bwd)");
     m.def("abi_version", []() { return fa_abi_version(); });
     m.def("build_info", []() { return std::string(fa_build_info()); });
     m.def("densify_copies", []() { return g_densify_copies.load(std::memory_order_relaxed); }, "number of hidden .contiguous() copies made so far (0 for addressable layouts)");

@@ -11,7 +11,10 @@ from . import _C
 
 
 class FlashAttnFunc(torch.autograd.Function):
-    """O = softmax(Q K^T / sqrt(d) + causal_mask) V on (batch, seqlen, heads, head_dim) tensors."""
+    """O = softmax(Q K^T / sqrt(d) + causal_mask) V on (batch, seqlen, heads, head_dim) tensors.
+
+    The Python form of the autograd node, kept as the readable statement of what ``_C.attn_autograd`` does (flash_api.cpp:FlashAttnNode);
+    ``flash_attn_func`` goes through the C++ node, which costs the host 42-52 us per forward + backward instead of ~85 (profiles/r4_host_overhead.log)."""
 
     @staticmethod
     def forward(ctx, q, k, v, causal):
@@ -64,8 +67,8 @@ def flash_attn_func(q, k, v, *legacy_dims, causal=False, return_lse=False):
     if return_lse:
         out, lse = _C.fwd(q, k, v, bool(causal))
         return out, lse
-    return FlashAttnFunc.apply(q, k, v, causal)
+    return _C.attn_autograd(q, k, v, bool(causal))
 
 
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False):
-    return FlashAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal)
+    return _C.attn_varlen_autograd(q, k, v, cu_seqlens_q, cu_seqlens_k, int(max_seqlen_q), int(max_seqlen_k), bool(causal))

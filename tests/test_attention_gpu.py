@@ -312,6 +312,48 @@ def test_flash_attn_func_autograd_and_strided_views(gpu):
         F.flash_attn_func(q, k, v, 9, 9, 9, 9)
 
 
+def test_autograd_nodes_give_the_bits_of_the_raw_entry_points(gpu):
+    """flash_attn_func / flash_attn_varlen_func run C++ autograd nodes (flash_api.cpp:FlashAttnNode, FlashAttnVarlenNode) since round 4: the same O and
+    the same gradients, bit for bit, as fwd + bwd / varlen_fwd + varlen_bwd called by hand and as the Python autograd.Function they replaced; no
+    gradient for the integer arguments; double use of one graph raises like any autograd node"""
+    import flash_attn_turing as F
+    from flash_attn_turing import interface
+
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    q, do = (torch.randn(2, 300, 6, 64, generator=gen).to(gpu, torch.bfloat16) for _ in range(2))
+    k, v = (torch.randn(2, 400, 2, 64, generator=gen).to(gpu, torch.bfloat16) for _ in range(2))
+    for causal in (False, True):
+        o, lse = F.fwd(q, k, v, causal)
+        grads = F.bwd(q, k, v, o, lse, do, causal)
+        for fn in (lambda a, b_, c: F.flash_attn_func(a, b_, c, causal=causal), lambda a, b_, c: interface.FlashAttnFunc.apply(a, b_, c, causal)):
+            qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+            out = fn(qg, kg, vg)
+            assert out.requires_grad and torch.equal(out.detach(), o)
+            out.backward(do)
+            for a_, b_ in zip(grads, (qg.grad, kg.grad, vg.grad)):
+                assert torch.equal(a_, b_)
+    # no graph when nothing requires grad; an inference-mode call works
+    assert not F.flash_attn_func(q, k, v, causal=True).requires_grad
+    with torch.inference_mode():
+        assert torch.equal(F.flash_attn_func(q, k, v, causal=True), F.fwd(q, k, v, True)[0])
+    # packed form
+    lens_q, lens_k = [5, 0, 130, 77], [9, 3, 130, 200]
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device=gpu)
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device=gpu)
+    qp, dop = (torch.randn(sum(lens_q), 4, 128, generator=gen).to(gpu, torch.float16) for _ in range(2))
+    kp, vp = (torch.randn(sum(lens_k), 2, 128, generator=gen).to(gpu, torch.float16) for _ in range(2))
+    o, lse = F.varlen_fwd(qp, kp, vp, cu_q, cu_k, max(lens_q), max(lens_k), True)
+    grads = F.varlen_bwd(qp, kp, vp, o, lse, dop, cu_q, cu_k, max(lens_q), max(lens_k), True)
+    qg, kg, vg = (t.clone().requires_grad_(True) for t in (qp, kp, vp))
+    out = F.flash_attn_varlen_func(qg, kg, vg, cu_q, cu_k, max(lens_q), max(lens_k), causal=True)
+    assert torch.equal(out.detach(), o)
+    out.backward(dop)
+    for a_, b_ in zip(grads, (qg.grad, kg.grad, vg.grad)):
+        assert torch.equal(a_, b_)
+    with pytest.raises(RuntimeError):
+        out.backward(dop)                       # the graph's buffers are freed after the first backward
+
+
 def test_error_behaviour_matches_reference_checks(gpu):
     import flash_attn_turing as F
 
