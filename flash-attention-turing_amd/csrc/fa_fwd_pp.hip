@@ -178,6 +178,20 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     }
 
     set_current(tile);
+    if (n_tiles == 0) {
+        // a block of rows that sees no key at all (causal with seqlen_q > seqlen_k, or an empty key sequence): O = 0, LSE = 0 (flash_fwd_kernel.h:718,767), written straight from
+        // registers - no Q load, no K / V tile, no LDS, no barrier (round 4: such a workgroup took ~38 us through the full prologue and epilogue, profiles/r4_fwd_dead_rows_ab.log)
+        const int rows_here = rows_of(tile);
+        const rsrc_t o_rs = make_rsrc(uniform_ptr(o_ptr_of(tile)), (uint32_t)(rows_here - 1) * o_rowb + ROWB);
+        constexpr int O_CHUNKS_DEAD = (32 * SLOTS) / 64;
+#pragma unroll
+        for (int i = 0; i < O_CHUNKS_DEAD; ++i) {
+            const int chunk = lane + i * 64, row = wave * 32 + chunk / SLOTS, slot = chunk % SLOTS;
+            buf_store16(o_rs, (uint32_t)row * o_rowb + slot * 16, u32x4{0u, 0u, 0u, 0u});      // rows >= rows_here fall outside the SRD
+        }
+        if (lane < 32 && wave * 32 + lane < rows_here) lse_bh[tile * kFwdBlockM + wave * 32 + lane] = 0.f;
+        return;
+    }
 
     u32x4 qf[KS];
     {

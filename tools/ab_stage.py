@@ -49,6 +49,10 @@ CONFIGS = {
     "bf16 d128 8k mqa causal b1": (1, 8192, 32, 1, 128, BF16, True),
     "bf16 d128 8k gqa4 causal": (4, 8192, 32, 4, 128, BF16, True),
     "bf16 d128 2k mqa": (1, 2048, 32, 1, 128, BF16, False),
+    "fp16 d128 sq8k sk1k causal": (4, 8192, 32, 32, 128, F16, True, 1024),
+    "fp16 d128 sq16k sk2k causal": (2, 16384, 32, 32, 128, F16, True, 2048),
+    "fp16 d64 sq8k sk1k causal": (4, 8192, 32, 32, 64, F16, True, 1024),
+    "fp16 d128 sq1k sk8k causal": (4, 1024, 32, 32, 128, F16, True, 8192),
 }
 
 
@@ -75,12 +79,14 @@ def main():
     libs = {f"{chr(65 + i)}:{os.path.basename(p)[6:-3]}": load(p) for i, p in enumerate(a.libs)}
     stages = a.stages.split(",")
     dev = torch.device("cuda:0")
-    for cname, (b, s, h, hk, d, dt, causal) in CONFIGS.items():
+    for cname, cfg in CONFIGS.items():
         if a.only and not any(x in cname for x in a.only.split(",")):
             continue
+        b, s, h, hk, d, dt, causal = cfg[:7]
+        sk = cfg[7] if len(cfg) > 7 else s          # (optional 8th entry: seqlen_k != seqlen_q)
         gen = torch.Generator(device=dev).manual_seed(1)
         q, do = (torch.randn(b, s, h, d, device=dev, dtype=dt, generator=gen) for _ in range(2))
-        k, v = (torch.randn(b, s, hk, d, device=dev, dtype=dt, generator=gen) for _ in range(2))
+        k, v = (torch.randn(b, sk, hk, d, device=dev, dtype=dt, generator=gen) for _ in range(2))
         o, dq = torch.empty_like(q), torch.empty_like(q)
         dk, dv = torch.empty_like(k), torch.empty_like(v)
         lse, dsum = (torch.empty(b, h, s, device=dev, dtype=torch.float32) for _ in range(2))
@@ -107,7 +113,8 @@ def main():
         torch.cuda.synchronize()
         ref = {}
         for stage in stages:
-            fl = 4.0 * b * h * s * s * d * (0.5 if causal else 1.0) * {"fwd": 1, "dq": 1.5, "dkdv": 2, "bwd": 2.5}[stage]
+            pairs = s * sk * (0.5 if causal else 1.0) if sk == s else (sum(max(0, min(sk, i + sk - s + 1)) for i in range(s)) if causal else s * sk)
+            fl = 4.0 * b * h * pairs * d * {"fwd": 1, "dq": 1.5, "dkdv": 2, "bwd": 2.5}[stage]
             times, outs = {n: [] for n in libs}, {}
 
             def run(n):
