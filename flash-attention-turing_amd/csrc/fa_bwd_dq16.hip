@@ -21,8 +21,8 @@ constexpr int kDq16Threads = 512;
 constexpr int kDq16BlockM = 256;
 constexpr int kDq16BlockN = 64;
 #ifndef FA_DQ16_ABL
-#define FA_DQ16_ABL 0         // timing-only ablations (results WRONG), bit mask: 1 the LDS-DMA of the next tile is not waited for, 2 no K / V row-fragment LDS reads, 4 no
-#endif                        // exponentials, 8 no transposed K reads (profiles/r4_bwd_dq16_ablations.log)
+#define FA_DQ16_ABL 0         // timing-only ablations (results may be WRONG): 1 = the LDS-DMA of the next tile is not waited for
+#endif
 #ifndef FA_DQ16_STAGGER_DMA
 #define FA_DQ16_STAGGER_DMA 1
 #endif
@@ -190,12 +190,8 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
                 for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-#if FA_DQ16_ABL & 2
-                        const u32x4 kf = qf[ks][kk], vf = dof[ks][kk];
-#else
                         const u32x4 kf = lds_read16(kbuf, row_rd[ks] + (2 * cch + kk) * 16 * ROWB);
                         const u32x4 vf = lds_read16(vbuf, row_rd[ks] + (2 * cch + kk) * 16 * ROWB);
-#endif
 #pragma unroll
                         for (int qb = 0; qb < 2; ++qb) {
                             sacc[kk][qb] = LP<T>::mfma16(kf, qf[ks][qb], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[kk][qb]);       // S^T = K Q^T
@@ -209,11 +205,7 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
 #pragma unroll
                     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-#if FA_DQ16_ABL & 4
-                        for (int r = 0; r < 4; ++r) sacc[kk][qb][r] = sacc[kk][qb][r] * 0.01f;
-#else
                         for (int r = 0; r < 4; ++r) sacc[kk][qb][r] = fast_exp2(__builtin_fmaf(sacc[kk][qb][r], c, -lse2[qb]));
-#endif
                 if (need_mask) {                                    // wave-uniform branch: interior tiles skip the 2 VALU per element
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk)
@@ -234,13 +226,9 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
                 // dQ^T (16-d blocks x 16 queries) += K^T (16 d x 32 keys) * dS^T (32 keys x 16 queries)
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-#if FA_DQ16_ABL & 8
-                    const u32x4 ktf = qf[db & 3][db >> 2];
-#else
                     const u32x2 a0 = lds_read_tr8(kbuf, tr_rd[db] + (32 * cch) * ROWB);
                     const u32x2 a1 = lds_read_tr8(kbuf, tr_rd[db] + (32 * cch + 16) * ROWB);
                     const u32x4 ktf = {a0.x, a0.y, a1.x, a1.y};
-#endif
                     dqacc[db][0] = LP<T>::mfma16(ktf, dsf[0], dqacc[db][0]);
                     dqacc[db][1] = LP<T>::mfma16(ktf, dsf[1], dqacc[db][1]);
                 }
