@@ -10,6 +10,13 @@ def test_module_surface_matches_reference_exports():
     for name in ("fwd", "bwd", "varlen_fwd", "varlen_bwd", "flash_attn_func"):
         assert callable(getattr(F, name))
     assert F.abi_version() == 4
+    # round 4: the differentiable wrappers run C++ autograd nodes of the host module; CPU tensors fail in the same loud way through them
+    assert callable(F._C.attn_autograd) and callable(F._C.attn_varlen_autograd)
+    x = torch.zeros(1, 8, 2, 128, dtype=torch.float16, requires_grad=True)
+    with pytest.raises(RuntimeError, match="GPU"):
+        F.flash_attn_func(x, x, x, causal=True)
+    with pytest.raises(RuntimeError, match="rank-3"):
+        F.flash_attn_varlen_func(x, x, x, torch.zeros(2, dtype=torch.int32), torch.zeros(2, dtype=torch.int32), 8, 8)
 
 
 def test_cpu_tensors_are_rejected_not_silently_computed():
