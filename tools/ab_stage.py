@@ -49,6 +49,10 @@ CONFIGS = {
     "bf16 d128 8k mqa causal b1": (1, 8192, 32, 1, 128, BF16, True),
     "bf16 d128 8k gqa4 causal": (4, 8192, 32, 4, 128, BF16, True),
     "bf16 d128 2k mqa": (1, 2048, 32, 1, 128, BF16, False),
+    "bf16 d128 2k": (4, 2048, 32, 32, 128, BF16, False),
+    "bf16 d128 4k": (4, 4096, 32, 32, 128, BF16, False),
+    "bf16 d128 16k": (2, 16384, 32, 32, 128, BF16, False),
+    "bf16 d128 8k gqa4": (4, 8192, 32, 8, 128, BF16, False),
     "fp16 d128 sq8k sk1k causal": (4, 8192, 32, 32, 128, F16, True, 1024),
     "fp16 d128 sq16k sk2k causal": (2, 16384, 32, 32, 128, F16, True, 2048),
     "fp16 d64 sq8k sk1k causal": (4, 8192, 32, 32, 64, F16, True, 1024),
