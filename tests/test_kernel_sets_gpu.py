@@ -64,8 +64,9 @@ def test_against_c_oracle(gpu, b, sq, sk, h, hk, d, causal, dtype, pinned_set):
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("d", [128, 64])
-@pytest.mark.parametrize("batch_size,nheads,nheads_k", [(1, 2, 1), (3, 6, 3), (3, 6, 1), (3, 4, 4), (1, 4, 4)])      # (batch 1 and 3 of every head layout run unpinned in tests/test_attention_gpu.py;
-def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, causal, pinned_set):                         #  the pinned passes keep one of each plus MHA at both: the suite's longest module)
+@pytest.mark.parametrize("batch_size", [1, 3])
+@pytest.mark.parametrize("nheads,nheads_k", [(2, 1), (6, 3), (6, 1), (4, 4)])
+def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, causal, pinned_set):
     _d64_only_once(d, pinned_set)
     TA.test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, causal)
 
