@@ -71,6 +71,33 @@ def _write_stamp(target, stamp_value):
         f.write(stamp_value)
 
 
+# Debug builds of the library for tests/test_dma_protocol_gpu.py (round 5): the LDS-DMA protocols of fa_fwd_pp16 and fa_bwd_dkdv16 under adversarial
+# timing.  Only the two sources that carry the switches are recompiled; everything else is the product's objects.  The product's ISA does not change.
+DEBUG_SOURCES = ["fa_fwd_pp16.hip", "fa_bwd_dkdv16.hip"]
+DEBUG_VARIANTS = {
+    "dma_late": ["-DFA_PP16_DMA_DEBUG=1", "-DFA_KV16_DMA_DEBUG=1"],          # every request issued directly in front of the wait that retires it
+    "dma_sleepy": ["-DFA_PP16_DMA_DEBUG=2", "-DFA_KV16_DMA_DEBUG=2"],        # group B / waves 4-7 sleep ~4000 cycles in front of every request
+    "dma_racy": ["-DFA_PP16_ROLE_DMA=0", "-DFA_PP16_RACY=1"],                # the documented WRONG counted-wait form of round 4, normal timing
+    "dma_racy_late": ["-DFA_PP16_ROLE_DMA=0", "-DFA_PP16_RACY=1", "-DFA_PP16_DMA_DEBUG=1"],      # ... under late issue: must FAIL
+}
+DEBUG_DIR = os.path.join(CSRC, "debug")
+
+
+def debug_library_path(name):
+    return os.path.join(DEBUG_DIR, f"libfa_{name}.so")
+
+
+M0_GUARD_SOURCES = ["fa_fwd_pp.hip", "fa_fwd_pp16.hip", "fa_bwd.hip", "fa_bwd_dq16.hip", "fa_bwd_dkdv16.hip"]
+
+
+def m0_uses_outside_asm(asm_text):
+    """mentions of the M0 register in gfx950 assembly outside `;;#ASMSTART .. ;;#ASMEND` blocks (= in code hipcc generated itself)"""
+    import re
+
+    outside = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", asm_text, flags=re.S)
+    return len(re.findall(r"\bm0\b", outside))
+
+
 def hipcc_path():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -99,13 +126,62 @@ def build_kernels(force=False):
             cmd.insert(1, digest_flag)
         print("[build]", " ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))
+    # M0 guard: every kernel issues its LDS-DMA from inline asm WITHOUT saving / restoring M0, which is only sound while nothing hipcc itself
+    # generates for those kernels touches M0 (no compiler-visible LDS-DMA, no indirect register indexing, no readlane-by-M0).  A different compiler or
+    # a future edit could change that silently, so the build looks: the device assembly of every kernel source, outside the hand-written
+    # `;;#ASMSTART .. ;;#ASMEND` statements, must not mention m0 (the same scan as tests/test_kernel_resources_cpu.py, here so that a wheel or an
+    # in-tree build made without running the tests cannot ship it).
+    scans = []
+    for s in srcs:
+        if os.path.basename(s) in M0_GUARD_SOURCES:
+            asm = s[:-4] + ".guard.s"
+            cmd = [hipcc_path()] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-I", CSRC, "-I", INCLUDE, "-Wno-unused-command-line-argument", "--cuda-device-only", "-S", s, "-o", asm]
+            scans.append((s, asm, subprocess.Popen(cmd)))
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
+    for s, asm, p in scans:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed (M0 guard pass)")
+        with open(asm) as f:
+            n = m0_uses_outside_asm(f.read())
+        os.remove(asm)
+        if n:
+            raise RuntimeError(f"{os.path.basename(s)}: {n} use(s) of M0 outside the hand-written asm statements - the unsaved-M0 LDS-DMA of these kernels is "
+                               "no longer safe with this compiler / this edit (fa_params.hpp FA_BWD_DMA_SAVE_M0, fa_device.hpp dma16_to_lds_hidden)")
     _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     _write_stamp(LIB_PATH, stamp)
     print(f"[build] {LIB_NAME} built in {time.time() - t0:.1f}s")
     return LIB_PATH
+
+
+def build_debug_variants(force=False):
+    """csrc/debug/libfa_<variant>.so: the product library with DEBUG_SOURCES rebuilt under a variant's switches (needs build_kernels() first)"""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    base = _digest(srcs + hdrs, " ".join(HIPCC_FLAGS) + repr(sorted(EXTRA_FLAGS.items())))
+    os.makedirs(DEBUG_DIR, exist_ok=True)
+    todo = [(n, f) for n, f in DEBUG_VARIANTS.items() if force or _stale(debug_library_path(n), base + repr(f))]
+    if not todo:
+        print("[build] debug variants up to date")
+        return
+    t0 = time.time()
+    procs = []
+    for n, flags in todo:
+        for s in DEBUG_SOURCES:
+            o = os.path.join(DEBUG_DIR, f"{n}_{s[:-4]}.o")
+            cmd = [hipcc_path()] + HIPCC_FLAGS + EXTRA_FLAGS.get(s, []) + flags + ["-I", CSRC, "-I", INCLUDE, "-c", os.path.join(CSRC, s), "-o", o]
+            procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed (debug variant)")
+    for n, flags in todo:
+        objs = [os.path.join(DEBUG_DIR, f"{n}_{s[:-4]}.o") if s in DEBUG_SOURCES else os.path.join(CSRC, s[:-4] + ".o") for s in HIP_SOURCES]
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", debug_library_path(n)] + objs)
+        _write_stamp(debug_library_path(n), base + repr(flags))
+        for s in DEBUG_SOURCES:
+            os.remove(os.path.join(DEBUG_DIR, f"{n}_{s[:-4]}.o"))
+    print(f"[build] {len(todo)} debug variant(s) built in {time.time() - t0:.1f}s")
 
 
 def build_torch_module(force=False):
@@ -139,6 +215,7 @@ def build_torch_module(force=False):
 
 def build_all(force=False, torch_module=True):
     build_kernels(force)
+    build_debug_variants(force)
     if torch_module:
         build_torch_module(force)
 

@@ -790,10 +790,34 @@ constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 20;       // seqlen_q * seql
                                                               // costs one XOR per base register and tile (profiles/r3_policy_sweep.log, second table:
                                                               // -2..-8 % from 1k on, +-1.5 % at 512); per head, not per launch: fa_fwd_pp.hip says why
 constexpr int64_t kDqMfma16MinPairsCausal = (int64_t)1 << 28;
+// head_dim 64 (round 5): both backward kernels also exist in the 16x16x32 tiling (fa_bwd_dq16.hip with 128-key tiles, fa_bwd_dkdv16.hip), one workgroup
+// per compute unit on 160-180 registers against two co-resident workgroups of the 32x32x16 kernels on 128.  Measured, interleaved, two boxes
+// (profiles/r5_bwd_d64_mfma16_ab.log, time 16 / 32 at b4 h32): dQ without a mask 0.92 / 0.96 / 0.92 / 0.91 / 0.89 / 0.89 at 512 .. 16k, under a causal mask
+// 0.96 / 1.03 / 0.99 / 0.92-0.96 / 0.90-0.92 at 1k .. 16k (b16 x 2k: 1.12-1.18, sq 8k sk 1k: 1.17: two co-resident workgroups hide each other's prologue and
+// epilogue and balance uneven tiles); dK/dV without a mask 0.97 / 1.01 / 0.97 / 0.95 / 0.94 / 0.95, under one 1.02 / 1.06 / 1.04 / 1.00-1.04 / 0.96-1.00.
+// FA_POLICY_AUTO follows those signs per head: seqlen_q * seqlen_k from which the 16x16x32 kernel serves (0 = never).
+#ifndef FA_BWD_D64_DQ16_MIN_PAIRS
+#define FA_BWD_D64_DQ16_MIN_PAIRS 1
+#endif
+#ifndef FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL
+#define FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL ((int64_t)1 << 26)
+#endif
+#ifndef FA_BWD_D64_DKDV16_MIN_PAIRS
+#define FA_BWD_D64_DKDV16_MIN_PAIRS ((int64_t)1 << 24)
+#endif
+#ifndef FA_BWD_D64_DKDV16_MIN_PAIRS_CAUSAL
+#define FA_BWD_D64_DKDV16_MIN_PAIRS_CAUSAL ((int64_t)1 << 28)
+#endif
 static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
     const int policy = kernel_policy();
-    if (kp.d != 128 || policy == 0) return false;
+    if ((kp.d != 128 && kp.d != 64) || policy == 0) return false;
     if (policy == 1) return true;
+    if (kp.d == 64) {
+        const int64_t min_pairs = dkdv ? (kp.is_causal ? (int64_t)FA_BWD_D64_DKDV16_MIN_PAIRS_CAUSAL : (int64_t)FA_BWD_D64_DKDV16_MIN_PAIRS)
+                                       : (kp.is_causal ? (int64_t)FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL : (int64_t)FA_BWD_D64_DQ16_MIN_PAIRS);
+        // (seqlen_k < seqlen_q under a mask: blocks of dead rows, where the narrow kernels are ahead)
+        return min_pairs > 0 && (int64_t)kp.seqlen_q * kp.seqlen_k >= min_pairs && !(kp.is_causal && kp.seqlen_k < kp.seqlen_q);
+    }
     // dQ: without a mask always; under a causal mask from 16k x 16k, where every box measured so far has it ahead (ratio 16 / 32 at 16k:
     // 0.99, 0.97, 0.94, 0.97; at 8k 0.98 .. 1.03: profiles/r3_policy_sweep.log, r4_policy_sweep_after_rowsum.log)
     if (!dkdv) return !kp.is_causal || (int64_t)kp.seqlen_q * kp.seqlen_k >= kDqMfma16MinPairsCausal;
@@ -806,7 +830,7 @@ hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kDqBlockM - 1) / kDqBlockM);
     kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kDqBlockM, kp.n_q_tiles) : 0u;
-    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, kp.varlen_slots != 0 ? kp.h : (int64_t)kp.b * kp.h, kp.seqlen_q, kp.seqlen_k, kp.n_q_tiles, kp.d == 64 ? 2 : 1, (int64_t)4 * kp.seqlen_k * kp.d);
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, kp.varlen_slots != 0 ? kp.h : (int64_t)kp.b * kp.h, kp.seqlen_q, kp.seqlen_k, kp.n_q_tiles, (kp.d == 64 && !bwd_use_mfma16(kp, false)) ? 2 : 1, (int64_t)4 * kp.seqlen_k * kp.d);
     if (bwd_use_mfma16(kp, false)) return launch_bwd_dq16(kp, dtype, s);
     return FA_DISPATCH(launch_dq_t, kp, dtype, s);
 }
@@ -863,7 +887,7 @@ hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t s) {
     kp.n_split = kp.ws != nullptr ? dkdv_split(kp, kp.ws_bytes) : 1;
     kp.ws_rows = dkdv_rows(kp);
     // (key block 0 is the heaviest under a causal mask: ascending tile order is heaviest first already)
-    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, (kp.varlen_slots != 0 ? (int64_t)1 : (int64_t)kp.b) * kp.h_k * kp.n_split, kp.seqlen_q, kp.seqlen_k, kp.n_k_tiles, kp.d == 64 ? 2 : 1, (int64_t)4 * kp.seqlen_q * kp.d * kp.h_ratio / kp.n_split);
+    kp.group_heads = causal_group_heads(kp.is_causal != 0, kp.varlen_slots != 0 ? kp.b : 0, (kp.varlen_slots != 0 ? (int64_t)1 : (int64_t)kp.b) * kp.h_k * kp.n_split, kp.seqlen_q, kp.seqlen_k, kp.n_k_tiles, (kp.d == 64 && !bwd_use_mfma16(kp, true)) ? 2 : 1, (int64_t)4 * kp.seqlen_q * kp.d * kp.h_ratio / kp.n_split);
     return FA_DISPATCH(launch_dkdv_t, kp, dtype, s);
 }
 

@@ -37,6 +37,9 @@ namespace fa {
 #ifndef FA_KV16_ABL
 #define FA_KV16_ABL 0         // timing-only ablations (results are WRONG), bit mask: 1 no workgroup barrier at the end of a tile, 2 no row-fragment LDS reads in the
 #endif                        // S / dP phase, 8 no exponentials, 16 no LDS-DMA of the next tile, 32 nothing of the next tile is waited for (no vmcnt wait in the loop at all; the statistics are not refreshed) (profiles/r4_bwd_dkdv16_ablations.log)
+#ifndef FA_KV16_DMA_DEBUG
+#define FA_KV16_DMA_DEBUG 0   // test builds only (tests/test_dma_protocol_gpu.py; the product is 0 and its ISA does not change): 1 = LATE ISSUE, the next tile's LDS-DMA goes
+#endif                        // out directly in front of the wait that retires it (the bytes land as late as the ring protocol can tolerate); 2 = waves 4-7 sleep ~4000 cycles first
 #ifndef FA_KV16_NOP_ONCE
 #define FA_KV16_NOP_ONCE 1    // the VALU -> MFMA source hazard of the asm-issued dV / dK MFMAs (P / dS come straight from v_cvt_pk) is padded once, in
 #endif                        // front of the phase, instead of with an s_nop in front of each of its 32 MFMAs: -0.2..-0.8 %
@@ -57,9 +60,22 @@ struct LP16<__bf16> {
     static FA_DEV void mfma_agpr(f32x4& acc, u32x4 a, u32x4 b) { asm(FA_KV16_NOP "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); }
 };
 
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdKernelParams p) {
-    constexpr int D = 128, KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;
+// FA_KV16_MIN_WAVES: waves per SIMD the register budget is cut for (head_dim 64, round 5: 2 = one workgroup per compute unit, accumulators in
+// 64 AGPRs + up to 192 VGPRs; 4 = two co-resident workgroups on 128 registers in all, what the 32x32x16 head_dim-64 kernel runs with)
+#ifndef FA_KV16_MIN_WAVES
+#define FA_KV16_MIN_WAVES(D) 2
+#endif
+#ifndef FA_KV16_D64_PF
+#define FA_KV16_D64_PF 2      // head_dim 64: transposed fragments in flight in the dV / dK phase (8 steps there; 2 against 4: -0.5..-2.5 %, profiles/r5_bwd_d64_mfma16_ab.log)
+#endif
+#ifndef FA_KV16_D64_VREG
+#define FA_KV16_D64_VREG 2    // head_dim 64: both k-steps of V live in registers next to both of K (16 + 16 registers)
+#endif
+
+template <typename T, int D, bool CAUSAL>
+__global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv16_kernel(const BwdKernelParams p) {
+    static_assert(D == 128 || D == 64, "head_dim");
+    constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;
     constexpr int KVB = kKvBlockN * ROWB;                   // the workgroup's K (or V) tile
     constexpr int TILEB = kKvBlockM * ROWB;                 // one Q (or dO) tile
     constexpr int STATB = 2 * kKvBlockM * 4;                // lse2 + dsum of one tile
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     // Q / dO ring reads as absolute LDS addresses of ring slot 0 with everything wave- or lane-dependent folded in; a read is base register +
     // immediate (dO = Q + 2 * TILEB), and the registers move to the other slot by flipping ONE address bit per tile: the slots are TILEB =
     // 2^14 apart and every offset inside a tile stays below that.  Same for the statistics ring (2^9 apart).
-    static_assert(TILEB == (1 << 14) && OFF_Q % (2 * TILEB) == 0 && OFF_DO == OFF_Q + 2 * TILEB && STATB == (1 << 9) && OFF_STAT % (2 * STATB) == 0, "slot toggle");
+    static_assert((TILEB & (TILEB - 1)) == 0 && OFF_Q % (2 * TILEB) == 0 && OFF_DO == OFF_Q + 2 * TILEB && STATB == (1 << 9) && OFF_STAT % (2 * STATB) == 0, "slot toggle");
     uint32_t rq[KS], rt[DB];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) rq[ks] = lds0 + OFF_Q + row_rd[ks] + (uint32_t)(32 * qh) * ROWB;
@@ -218,7 +234,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
     __syncthreads();
 
     // B operands that never change: this wave's K fragments (all 4 k-steps, both key columns) and the first VREG k-steps of V
-    constexpr int VREG = FA_KV16_VREG(CAUSAL) < KS ? FA_KV16_VREG(CAUSAL) : KS;
+    constexpr int VREG_WANT = D == 64 ? FA_KV16_D64_VREG : FA_KV16_VREG(CAUSAL);
+    constexpr int VREG = VREG_WANT < KS ? VREG_WANT : KS;
     u32x4 kreg[KS][2], vreg[VREG > 0 ? VREG : 1][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
         FA_LDS char* sbuf = stat + buf * STATB;
 #endif
         const bool more = (it + 1 < n_iters);
-#if !(FA_KV16_ABL & 16)
+#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
         if (more && (FA_KV16_DMA_EARLY == 2 || qh == FA_KV16_DMA_EARLY)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
 #endif
         // Only the two statistics waves need this load, and a vector-memory instruction costs its wave ~100 cycles whatever it returns.  A LANE-dependent condition
@@ -315,10 +332,15 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
                         dpacc[i][kc] = LP<T>::mfma16(da[i], vf[kc], ks == 0 ? nd4[i] : dpacc[i][kc]);                              // dP - D = dO V^T - D
                     }
             }
-#if !(FA_KV16_ABL & 16)
+#if FA_KV16_DMA_DEBUG == 2
+            if (more && qh == 1) asm volatile("s_sleep 64" ::: "memory");
+#endif
+#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
             if (more && FA_KV16_DMA_EARLY != 2 && qh == (FA_KV16_DMA_EARLY ^ 1)) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
 #endif
+#if FA_KV16_DMA_DEBUG != 1
             if (more) pf_advance();
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #if FA_KV16_TOGGLE
@@ -359,7 +381,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
             }
             // dV^T += dO^T P and dK^T += Q^T dS: 2*DB fragments (transposed LDS reads), each feeding the two key columns.  The accumulators
             // are inline-asm operands, so the reads are software-pipelined by hand - fragment j + PF is requested before the MFMAs of j.
-            constexpr int NST = 2 * DB, PF = FA_KV16_PF;            // step j = (db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
+            constexpr int NST = 2 * DB, PF = D == 64 ? FA_KV16_D64_PF : FA_KV16_PF;            // step j = (db, which): which 0 -> dV (dO^T), 1 -> dK (Q^T)
             auto rd_frag = [&](int j) {
                 const int db = j >> 1;
 #if FA_KV16_TOGGLE
@@ -390,6 +412,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if FA_KV16_DMA_DEBUG == 1
+        if (more) { issue_tile(buf ^ 1); pf_advance(); }
+#endif
 #if !(FA_KV16_ABL & 32)
         if (more && wave < 2) store_stat(st_next, buf ^ 1);
         asm volatile("" :: "v"(st_next));               // consumed on every path: hipcc never has to guard the register at the loop top
@@ -490,12 +515,22 @@ __global__ __launch_bounds__(kKvThreads, 2) void fa_bwd_dkdv16_kernel(const BwdK
 }
 
 hipError_t launch_bwd_dkdv16(const BwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t s) {
+    if (kp.d == 64) {      // round 5: the same kernel at head_dim 64
+        if (dtype == 0) {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<_Float16, 64, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+            else hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<_Float16, 64, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        } else {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<__bf16, 64, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+            else hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<__bf16, 64, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        }
+        return hipGetLastError();
+    }
     if (dtype == 0) {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<_Float16, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-        else hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<_Float16, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<_Float16, 128, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        else hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<_Float16, 128, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
     } else {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<__bf16, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
-        else hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<__bf16, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<__bf16, 128, true>), dim3(grid), dim3(kKvThreads), 0, s, kp);
+        else hipLaunchKernelGGL((fa_bwd_dkdv16_kernel<__bf16, 128, false>), dim3(grid), dim3(kKvThreads), 0, s, kp);
     }
     return hipGetLastError();
 }

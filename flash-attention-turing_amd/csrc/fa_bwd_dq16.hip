@@ -19,7 +19,10 @@ namespace fa {
 
 constexpr int kDq16Threads = 512;
 constexpr int kDq16BlockM = 256;
-constexpr int kDq16BlockN = 64;
+// keys per tile: 64 at head_dim 128; head_dim 64 (round 5) also takes 128-key tiles (the same 16 KiB tile images, half the barriers per key)
+#ifndef FA_DQ16_D64_BN
+#define FA_DQ16_D64_BN 128
+#endif
 #ifndef FA_DQ16_ABL
 #define FA_DQ16_ABL 0         // timing-only ablations (results may be WRONG): 1 = the LDS-DMA of the next tile is not waited for
 #endif
@@ -27,9 +30,17 @@ constexpr int kDq16BlockN = 64;
 #define FA_DQ16_STAGGER_DMA 1
 #endif
 
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdKernelParams p) {
-    constexpr int D = 128, KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;
+// FA_DQ16_MIN_WAVES: waves per SIMD the register budget is cut for.  head_dim 64 (round 5): 2 = one workgroup per compute unit on up to 256 registers,
+// 4 = two co-resident workgroups on 128 (what the 32x32x16 head_dim-64 kernel runs with).
+#ifndef FA_DQ16_MIN_WAVES
+#define FA_DQ16_MIN_WAVES(D) 2
+#endif
+
+template <typename T, int D, bool CAUSAL, int BN>
+__global__ __launch_bounds__(kDq16Threads, FA_DQ16_MIN_WAVES(D)) void fa_bwd_dq16_kernel(const BwdKernelParams p) {
+    static_assert(D == 128 || D == 64, "head_dim");
+    constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;
+    constexpr int kDq16BlockN = BN;
     constexpr int NC = kDq16BlockN / 32;                                 // 32-key chunks (two 16-key score blocks each) per tile
     constexpr int TILEB = kDq16BlockN * ROWB;
     __shared__ __attribute__((aligned(16))) char smem_raw[(4 * TILEB > kDq16BlockM * ROWB) ? 4 * TILEB : kDq16BlockM * ROWB];
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
 
     // LDS-DMA staging (hand-issued, fa_device.hpp:dma16_to_lds_hidden): wave w moves the DPW 1-KiB pieces [w*DPW, (w+1)*DPW) of every K
     // and V tile; the swizzle is applied to the source offset.  Buffers: K0 K1 V0 V1.
-    constexpr int DPW = SLOTS / 8;
+    constexpr int DPW = BN * SLOTS / 512;
     uint32_t dma_goff_k[DPW], dma_goff_v[DPW];
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
@@ -270,12 +281,22 @@ __global__ __launch_bounds__(kDq16Threads, 2) void fa_bwd_dq16_kernel(const BwdK
 hipError_t launch_bwd_dq16(const BwdKernelParams& kp, int dtype, hipStream_t s) {
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     if (grid == 0) return hipSuccess;
+    if (kp.d == 64) {      // round 5: the same kernel at head_dim 64 (8 KiB tiles, 2 k-steps, 4 d blocks)
+        if (dtype == 0) {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq16_kernel<_Float16, 64, true, FA_DQ16_D64_BN>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+            else hipLaunchKernelGGL((fa_bwd_dq16_kernel<_Float16, 64, false, FA_DQ16_D64_BN>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+        } else {
+            if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq16_kernel<__bf16, 64, true, FA_DQ16_D64_BN>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+            else hipLaunchKernelGGL((fa_bwd_dq16_kernel<__bf16, 64, false, FA_DQ16_D64_BN>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+        }
+        return hipGetLastError();
+    }
     if (dtype == 0) {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq16_kernel<_Float16, true>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
-        else hipLaunchKernelGGL((fa_bwd_dq16_kernel<_Float16, false>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq16_kernel<_Float16, 128, true, 64>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+        else hipLaunchKernelGGL((fa_bwd_dq16_kernel<_Float16, 128, false, 64>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
     } else {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq16_kernel<__bf16, true>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
-        else hipLaunchKernelGGL((fa_bwd_dq16_kernel<__bf16, false>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+        if (kp.is_causal) hipLaunchKernelGGL((fa_bwd_dq16_kernel<__bf16, 128, true, 64>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
+        else hipLaunchKernelGGL((fa_bwd_dq16_kernel<__bf16, 128, false, 64>), dim3(grid), dim3(kDq16Threads), 0, s, kp);
     }
     return hipGetLastError();
 }

@@ -56,9 +56,29 @@ constexpr float kPpDeferLog2 = 6.0f;
 #ifndef FA_PP16_EXACT_TILES
 #define FA_PP16_EXACT_TILES 16
 #endif
+#ifndef FA_PP16_EXACT_TILES_BF16
+#define FA_PP16_EXACT_TILES_BF16 64      // (only with FA_PP16_MFMA_ROWSUM == 2)
+#endif
 #ifndef FA_PP16_ABL
 #define FA_PP16_ABL 0       // timing-only ablations (results WRONG), bit mask: 1 the steady loop does not wait for its LDS-DMA, 2 does not issue it, 4 no exponentials (one multiply
 #endif                      // per score instead of fma + exp), 8 no LDS fragment reads in the matrix phases (profiles/r4_fwd_pp16_ablations.log)
+// FA_PP16_DMA_DEBUG (round 5; test builds only, the product is 0 and its ISA does not change): adversarial timing for the LDS-DMA protocol of the
+// unrolled steady loop.  A race of the class "a consumer reads a ring slot before the wait + barrier that publishes the producer's pieces" is invisible
+// to every value test as long as the DMA is usually early (profiles/r4_fwd_counted_wait_racy_form_ab.log was bit-identical on every shape and wrong).
+//   1 = LATE ISSUE: every request of the loop is issued at the last point the protocol itself allows - directly in front of the wait that retires it
+//       (followed by vmcnt(0)): the bytes land as late as a correct protocol can tolerate, a wrong one reads the slot's previous tenant;
+//   2 = SLEEPY GROUP: group B's waves sleep ~4000 cycles (more than a tile period) in front of every request.
+// FA_PP16_RACY (test builds only, with FA_PP16_ROLE_DMA=0): the documented WRONG form - symmetric roles, K(u+2) left in flight across the barrier and
+// retired by a counted wait at the end of the NEXT softmax phase - kept so that tests/test_dma_protocol_gpu.py can show the late-issue build catches it.
+#ifndef FA_PP16_DMA_DEBUG
+#define FA_PP16_DMA_DEBUG 0
+#endif
+#ifndef FA_PP16_RACY
+#define FA_PP16_RACY 0
+#endif
+#if FA_PP16_RACY && FA_PP16_ROLE_DMA
+#error "FA_PP16_RACY is the symmetric-role form: build with -DFA_PP16_ROLE_DMA=0"
+#endif
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
@@ -563,6 +583,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             // group A: K(u+2) -> the slot K(u-1) left (last read in M(u-1), which group B finished one barrier ago);
             // group B: V(u+2) -> the slot V(u-1) left (last read in M(u), which group B itself has just finished and group A one phase earlier).
             // Retired: the tile requested one softmax phase ago (K(u+1) / V(u+1)), by count - this phase's four pieces stay in flight.
+#if FA_PP16_DMA_DEBUG == 1
+            // LATE ISSUE: the request the counted wait of this phase would retire (tile u+1, made one phase ago in the product) goes out here instead
+            softmax_step(uu, no{}, no{}, mlc);
+            m_prefetch(S_U, S_UP1);
+            dma_role_tile(uu + 1, S_UP1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#else
+#if FA_PP16_DMA_DEBUG == 2
+            if (group == 1) asm volatile("s_sleep 64" ::: "memory");
+#endif
 #if !(FA_PP16_ABL & 2)
             dma_role_tile(uu + 2, S_UM1);
 #endif
@@ -572,6 +603,26 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
 #endif
             __syncthreads();
+#endif
+#elif FA_PP16_RACY
+            // the WRONG form (see the header): V(u+1) first so that the K(u+2) pieces are the youngest; the counted wait retires V(u+1) and the K(u+1)
+            // pieces of the PREVIOUS phase and leaves K(u+2) in flight across the barrier - but the other group's half of K(u+2) is then retired
+            // one barrier after this group starts reading the tile
+#if FA_PP16_DMA_DEBUG == 1
+            softmax_step(uu, no{}, no{}, mlc);
+            m_prefetch(S_U, S_UP1);
+            dma_v_tile(v_srd, uu + 1, S_UP1);
+            dma_k_tile(k_srd, uu + 1, S_UP1);      // (late issue: the K request this phase's counted wait retires)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#else
+            dma_v_tile(v_srd, uu + 1, S_UP1);
+            dma_k_tile(k_srd, uu + 2, S_UM1);
+            softmax_step(uu, no{}, no{}, mlc);
+            m_prefetch(S_U, S_UP1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+            __syncthreads();
+#endif
 #else
             if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
             if (uu + 1 < n_tiles) dma_v_tile(v_srd, uu + 1, S_UP1);
@@ -590,7 +641,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         if (role_loop && group == 1) dma_role_tile(2, 2);
 #endif
         // ring slot of tile u is u % 3: three steps per trip make every slot a constant
-        constexpr int kExactTiles = FA_PP16_EXACT_TILES * 64 / BN;      // (counted in 64-key tiles: the same 1024 keys for any tile width)
+        // (counted in 64-key tiles: the same 1024 keys for any tile width; bf16, whose P rounds to 8 bits, rides on a longer exact prefix)
+        constexpr int kExactTiles = (std::is_same<T, _Float16>::value ? FA_PP16_EXACT_TILES : FA_PP16_EXACT_TILES_BF16) * 64 / BN;
         constexpr int kExact = ML ? 1 + 3 * ((kExactTiles + 1) / 3) : 0;      // first MFMA-summed tile: start of a trip (16 for the default)
         if constexpr (ML) {
             for (; u + 3 <= n_main && u + 3 <= kExact; u += 3) {      // exactly summed tiles
@@ -620,7 +672,15 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #if FA_PP16_ROLE_DMA
         // leaving it: this wave's last request (one tile ahead of what the symmetric code below assumes; that code requests the tile again, the
         // same bytes into the same slot) is retired here; the next barrier publishes it long before its first read
+#if FA_PP16_DMA_DEBUG == 1
+        if (role_loop && u > 1) dma_role_tile(u + 1, ring_up1);      // (late issue: the product requested this tile in the loop's last step)
+#endif
         if (role_loop) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif FA_PP16_RACY
+#if FA_PP16_DMA_DEBUG == 1
+        if (u > 1) dma_k_tile(k_srd, u + 1, ring_up1);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         for (; u < n_main; ++u) {                 // the last one or two steady-state tiles
             m_phase(ring_um1, ring_u, prev_ml);

@@ -18,6 +18,9 @@ def _first_existing(*candidates):
 
 # installed package (setup.py ships library and header inside it) first, then the in-tree build
 LIBRARY_PATH = _first_existing(os.path.join(_HERE, "libflash_attn_gfx950.so"), os.path.join(os.path.dirname(_HERE), "csrc", "libflash_attn_gfx950.so"))
+# development aid (tools/ only: A/B and error-distribution scripts drive a variant build through this binding); the host module `_C` links the product library
+if os.environ.get("FA_GFX950_LIBRARY"):
+    LIBRARY_PATH = os.path.abspath(os.environ["FA_GFX950_LIBRARY"])
 HEADER_PATH = _first_existing(os.path.join(_HERE, "include", "flash_attn_gfx950.h"),
                               os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "flash_attn_gfx950.h"))
 
@@ -79,6 +82,10 @@ def lib():
         if not os.path.exists(LIBRARY_PATH):
             raise ImportError(f"{LIBRARY_PATH} missing: run `python flash-attention-turing_amd/build.py`")
         L = ctypes.CDLL(LIBRARY_PATH)
+        # a stale build of the same ABI number can lack the (additive) exports this binding needs: say so instead of failing on first use
+        missing = [n for n in declared_functions() if not hasattr(L, n)]
+        if missing:
+            raise ImportError(f"{LIBRARY_PATH} lacks {missing}: stale build, run `python flash-attention-turing_amd/build.py --force`")
         L.fa_abi_version.restype = ctypes.c_int
         L.fa_last_error.restype = ctypes.c_char_p
         L.fa_build_info.restype = ctypes.c_char_p

@@ -213,9 +213,15 @@ const char* fa_fwd_kernel_name(int32_t d);
  * (batch, head) shard of a problem gets the bits the whole problem gets (one exception: dK / dV of a GQA / MQA call that is given a
  * workspace - how far a head group is split, hence the order its partial sums are added in, follows the launch's workgroup count and the
  * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit); FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
- * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has one backward set (not affected) and, since round 4,
- * both forward kernels: FA_POLICY_AUTO sends fp16 problems from 2^24 pairs per head (2^26 causal) to the 16x16x32 one, whose softmax row sums
- * ride the matrix pipe (-2..5 %), and keeps bf16 on the 32x32x16 one; the pinned policies apply to both dtypes.  The reference has no counterpart. */
+ * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has both forward kernels since round 4 - FA_POLICY_AUTO sends fp16
+ * problems from 2^24 pairs per head (2^26 causal) to the 16x16x32 one, whose softmax row sums ride the matrix pipe (-2..5 %), and keeps bf16 on the
+ * 32x32x16 one - and both backward sets since round 5: FA_POLICY_AUTO gives dQ to the 16x16x32 kernel without a mask at every length and under a
+ * causal mask from 2^26 pairs per head, dK/dV from 2^24 (2^28 causal), never when a causal problem has fewer keys than queries (-8..-11 % / -4..-6 %
+ * where it serves; both dtypes).  The pinned policies apply to every head_dim, stage and dtype.  The reference has no counterpart.
+ * Precision contract of the forward's softmax row sums: fp16 inputs on the 16x16x32 kernel sum the ROUNDED P in the matrix pipe after an exactly
+ * summed prefix of 1024 keys (LSE within 5e-5 of fp32 math at the BASELINE sizes); bf16 inputs keep exact fp32 VALU sums on every kernel (LSE within
+ * 2e-6): with bf16's 8-bit P the same construction measured 1.2e-4 even behind a 4096-key exact prefix, for -0.9 % at configs[3] - refused
+ * (profiles/r5_fwd_bf16_mfma_rowsum_ab.log, r5_lse_error_bf16_mfma_rowsum.json). */
 #define FA_POLICY_MFMA32 0
 #define FA_POLICY_MFMA16 1
 #define FA_POLICY_AUTO 2

@@ -20,6 +20,8 @@ TOL = {
 }
 LSE_TOL = 1e-3
 ORACLE_OWN_CAP = 25      # check_mean_rel: the C oracle's own raw mean_rel may be at most this many times the plain tolerance
+ORACLE_BOUND_CAP = 10    # ... and a bound derived from it at most this many times the plain tolerance (was 2 x ORACLE_OWN_CAP = 50 everywhere),
+ORACLE_TINY_SK = 4       # except on problems of at most this many keys, where the reference algorithm itself reaches 0.18-0.23 (dQ at sk = 2) and 2 x its own stands
 REL_EPS = 1e-6
 
 
@@ -81,7 +83,8 @@ def check_mean_rel(xa, e, dtype, name, scale, sk, oracle, e_unrounded=None):
                      oracle's own raw mean_rel against the same expectation): where the reference algorithm itself meets 1e-2 the
                      kernel must meet the plain bound, where it provably cannot (a handful of keys: nothing averages the rounding of
                      P / dS out; tools/mean_rel_oracle_table.py prints the oracle's side on the dev container) the kernel may be
-                     at most twice as far off as the algorithm is.
+                     at most twice as far off as the algorithm is - but never more than ORACLE_BOUND_CAP (10) x the plain bound unless the
+                     problem has at most ORACLE_TINY_SK (4) keys (round 5; until then 50 x everywhere).
       rule "plain":  no oracle result (large problems) and sk >= 64: the plain bound.
       rule "zero":   the expectation is identically ~0 (max |e| < 1e-4): a single visible key makes dS = P (dP - D) vanish
                      analytically, the oracle returns exact zeros, and ANY fp32 implementation that forms D = rowsum(dO * O) and
@@ -118,7 +121,8 @@ def check_mean_rel(xa, e, dtype, name, scale, sk, oracle, e_unrounded=None):
         # is 0.23 (dQ, sq = sk = 2, fp16); an oracle that drifts past ORACLE_OWN_CAP x the plain tolerance fails here instead of silently
         # loosening every bound derived from it, and no derived bound exceeds 2 x that
         assert o_raw <= ORACLE_OWN_CAP * tol, f"{name}: the ORACLE's own raw mean_rel {o_raw:.3e} exceeds {ORACLE_OWN_CAP} x {tol:.1e} - oracle drift?"
-        bound = min(max(tol, 2.0 * o_raw), 2.0 * ORACLE_OWN_CAP * tol)
+        cap = 2.0 * ORACLE_OWN_CAP if (sk is not None and sk <= ORACLE_TINY_SK) else float(ORACLE_BOUND_CAP)
+        bound = min(max(tol, 2.0 * o_raw), cap * tol)
         row.update(rule="oracle", oracle=o_raw, bound=bound)
         assert k_raw <= bound, f"{name} raw mean_rel={k_raw:.3e} > max({tol:.1e}, 2 x oracle's {o_raw:.3e})"
     elif sk is not None and sk >= PLAIN_SK_MIN:

@@ -36,18 +36,24 @@ def pytest_sessionfinish(session, exitstatus):
     os.makedirs(out, exist_ok=True)
     if U.REL_TABLE:
         # every mean_rel decision of the run (tests/_util.py:check_mean_rel): kernel's and oracle's raw metric, bound, rule
-        rules = {}
+        rules, fams = {}, {}
         for r in U.REL_TABLE:
             s = rules.setdefault(r["rule"], dict(cases=0, worst_kernel=0.0, worst_ratio_to_bound=0.0))
             s["cases"] += 1
             s["worst_kernel"] = max(s["worst_kernel"], r["kernel"])
             if r.get("bound"):
-                s["worst_ratio_to_bound"] = max(s["worst_ratio_to_bound"], r.get("floored", r["kernel"]) / r["bound"])
+                # the ASSERTED quantity (the all-element raw value read as a failed assertion that was not one): the floored mean under rule
+                # "floor", otherwise the mean over the elements that carry relative information (tests/_util.py:check_mean_rel, `kernel_on_nonzero`)
+                s["worst_ratio_to_bound"] = max(s["worst_ratio_to_bound"], r.get("floored", r.get("kernel_on_nonzero", r["kernel"])) / r["bound"])
+            f = fams.setdefault(r["family"].split("[")[0], dict(cases=0, over_plain_bound=0, zero=0))
+            f["cases"] += 1
+            f["over_plain_bound"] += int(r["kernel"] > U.TOL[r["dtype"]]["mean_rel"])
+            f["zero"] += int(r["rule"] == "zero")
         over = [r for r in U.REL_TABLE if r["kernel"] > U.TOL[r["dtype"]]["mean_rel"]]
         with open(os.path.join(out, "mean_rel_table.json"), "w") as f:
             json.dump({"what": "raw mean_rel = mean(|x - e| / max(|e|, 1e-6)) (reference test_flash_attn.py:51-71,117,412) per asserted tensor; "
                                "`over_plain_bound` lists EVERY case whose raw kernel value exceeds the plain bound, with the oracle's value and the rule that applied",
-                       "exit_status": int(exitstatus), "n_cases": len(U.REL_TABLE), "by_rule": rules, "over_plain_bound": over}, f, indent=1)
+                       "exit_status": int(exitstatus), "n_cases": len(U.REL_TABLE), "by_rule": rules, "by_family": fams, "over_plain_bound": over}, f, indent=1)
     doc = {"what": "worst raw max_abs / mean_abs / mean_rel (reference test_flash_attn.py:51-71 metrics, expectation rounded to the output "
                    "format, NO slack) per test family and tensor; plain_bound_cases = cases (sk >= 64) on which the reference's plain "
                    "bounds max_abs <= 5e-3, mean_abs <= 2e-4 (x8 for bf16) were asserted",

@@ -187,6 +187,75 @@ def test_varlen_random_lengths_vs_torch_fp32(gpu, nheads, nheads_k, d, causal):
             assert (lse[i, :, lq[i]:] == 0).all(), "padded LSE must stay zero"
 
 
+# the reference's packed-sequence grid, de-duplicated (reference test_flash_attn.py:583-662: 80 parametrised (max_seqlen_q, max_seqlen_k) pairs, 58 unique:
+# the dense grid's 57 plus (4, 4))
+REF_VARLEN_PAIRS = sorted(set(REF_PAIRS) | {(4, 4)})
+
+
+def varlen_lengths(rng, batch, max_q, max_k):
+    """per-sequence lengths as the reference draws them (test_flash_attn.py:666-680): uniform in [1, max], then one sequence forced to max_seqlen_q and
+    - when there is more than one - a DIFFERENT one to max_seqlen_k"""
+    lq, lk = rng.integers(1, max_q + 1, batch), rng.integers(1, max_k + 1, batch)
+    iq = int(rng.integers(batch))
+    ik = iq
+    if batch > 1:
+        ik = int(rng.integers(batch - 1))
+        ik += ik >= iq
+    lq[iq], lk[ik] = max_q, max_k
+    return lq, lk
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("batch_size", [1, 3])
+@pytest.mark.parametrize("nheads,nheads_k", [(2, 1), (4, 2), (6, 3), (6, 1)])
+def test_reference_varlen_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, causal):
+    """The reference's own varlen parametrisation (test_flash_attn.py:575-662: every (max_seqlen_q, max_seqlen_k) pair x batch {1, 3} x its four head
+    pairs x head_dim {64, 128} x causal), restated pair for pair like the dense grid above: seeded random lengths with one sequence forced to each
+    maximum, the expectation computed PER SEQUENCE (C oracle with the reference's rounding points for small problems, fp32 math otherwise), padded
+    LSE entries zero.  All pairs of one (batch, heads, d, causal) run in one test body.  The host module passes total_q / total_k, so unequal
+    lengths go through the compact launch grid (and, under a causal mask, its heavy-first lookup)."""
+    import flash_attn_turing as F
+
+    from oracle import attn_oracle as A
+
+    rng = np.random.default_rng(4321 + 11 * nheads + 3 * nheads_k + d + 7 * batch_size + int(causal))
+    n = lambda t: t.float().cpu().numpy()
+    for max_q, max_k in REF_VARLEN_PAIRS:
+        lq, lk = varlen_lengths(rng, batch_size, max_q, max_k)
+        cu_q = np.concatenate([[0], np.cumsum(lq)]).astype(np.int32)
+        cu_k = np.concatenate([[0], np.cumsum(lk)]).astype(np.int32)
+        gen = torch.Generator(device="cpu").manual_seed(int(cu_q[-1]) * 131 + int(cu_k[-1]) + max_q)
+        q = torch.randn(int(cu_q[-1]), nheads, d, generator=gen).to(gpu, torch.float16)
+        k = torch.randn(int(cu_k[-1]), nheads_k, d, generator=gen).to(gpu, torch.float16)
+        v = torch.randn(int(cu_k[-1]), nheads_k, d, generator=gen).to(gpu, torch.float16)
+        do = torch.randn(int(cu_q[-1]), nheads, d, generator=gen).to(gpu, torch.float16)
+        cq, ck = torch.from_numpy(cu_q).to(gpu), torch.from_numpy(cu_k).to(gpu)
+        o, lse = F.varlen_fwd(q, k, v, cq, ck, max_q, max_k, causal)
+        dq, dk, dv = F.varlen_bwd(q, k, v, o, lse, do, cq, ck, max_q, max_k, causal)
+        assert lse.shape == (batch_size, nheads, max_q)
+        for i in range(batch_size):
+            qs, ks = slice(cu_q[i], cu_q[i + 1]), slice(cu_k[i], cu_k[i + 1])
+            qi, ki, vi, doi = q[qs][None], k[ks][None], v[ks][None], do[qs][None]
+            tag = f"max=({max_q},{max_k}) seq{i} lq={lq[i]} lk={lk[i]}"
+            if int(lq[i]) * int(lk[i]) <= 256 * 257:
+                # small problems: the C oracle with the reference's rounding points is the expectation (as in the dense grid), exact fp64 math for mean_rel
+                o_n, lse_n = A.attn_fwd(n(qi), n(ki), n(vi), causal=causal, round_mode=A.ROUND_FP16)
+                dq_n, dk_n, dv_n = A.attn_bwd(n(qi), n(ki), n(vi), o_n, lse_n, n(doi), causal=causal, round_mode=A.ROUND_FP16)
+                refs = dict(O=o_n[0], dQ=dq_n[0], dK=dk_n[0], dV=dv_n[0])
+                lse_r = torch.from_numpy(lse_n)[0]
+                xo, _, xdq, xdk, xdv = U.torch_attention_ref(qi, ki, vi, doi, causal, device="cpu", dtype=torch.float64)
+                extra = {t: dict(oracle=refs[t], exact=x[0].cpu().numpy()) for t, x in (("O", xo), ("dQ", xdq), ("dK", xdk), ("dV", xdv))}
+            else:
+                o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(qi, ki, vi, doi, causal)
+                refs = dict(O=o_r[0].cpu().numpy(), dQ=dq_r[0].cpu().numpy(), dK=dk_r[0].cpu().numpy(), dV=dv_r[0].cpu().numpy())
+                lse_r, extra = lse_r[0].cpu(), {t: {} for t in refs}
+            for got, t in ((o[qs], "O"), (dq[qs], "dQ"), (dk[ks], "dK"), (dv[ks], "dV")):
+                U.assert_close(n(got), refs[t], "fp16", f"{t} {tag}", sk=int(lk[i]), **extra[t])
+            assert (lse[i, :, : lq[i]].cpu() - lse_r).abs().max().item() <= U.LSE_TOL, "LSE " + tag
+            assert (lse[i, :, lq[i]:] == 0).all(), "padded LSE must stay zero: " + tag
+
+
 def test_bf16_backward_medium(gpu):
     import flash_attn_turing as F
 

@@ -50,7 +50,13 @@ def test_forward_kernel_policy_is_host_state():
     # per head, not per launch: a (batch, head) shard gets the kernel of the whole problem
     assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == capi.kernel_name("fwd", 64, 16384, 16384, 64, 128, True) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("dkdv", 1, 8192, 8192, 2, 128, True) == "fa_bwd_dkdv16_kernel"
-    assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, False) == "fa_bwd_dkdv_kernel"
+    # head_dim 64 backward (round 5): dQ 16x16x32 without a mask at every length and under one from 2^26 pairs per head; dK/dV from 2^24 (2^28 causal);
+    # never when a causal problem has fewer keys than queries (dead row blocks); both dtypes
+    assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, False) == capi.kernel_name("dkdv", 1, 4096, 4096, 1, 64, False, "bf16") == "fa_bwd_dkdv16_kernel"
+    assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 64, False) == capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, True) == "fa_bwd_dkdv_kernel"
+    assert capi.kernel_name("dkdv", 4, 16384, 16384, 32, 64, True) == "fa_bwd_dkdv16_kernel"
+    assert capi.kernel_name("dq", 4, 512, 512, 32, 64, False) == capi.kernel_name("dq", 4, 8192, 8192, 32, 64, True) == "fa_bwd_dq16_kernel"
+    assert capi.kernel_name("dq", 4, 4096, 4096, 32, 64, True) == capi.kernel_name("dq", 4, 16384, 8192, 32, 64, True) == "fa_bwd_dq_kernel"
     assert capi.lib().fa_kernel_name(9, 1, 1, 1, 1, 128, 0) == b""
 
 

@@ -171,3 +171,68 @@ def test_clockbench_parser_reads_the_current_table_and_reports_drift():
     old_format = "MFMA only, 2 waves/SIMD, all CUs   5.1 ms  s_memtime 8e6 ticks -> 1.6 GHz ; 1650 TFLOP/s ; 32 ticks/MFMA/SIMD\n"
     assert "error" in bench.parse_clockbench(old_format)
     assert "error" in bench.parse_clockbench("")
+
+
+def test_ceiling_block_decomposes_the_gap_to_peak():
+    """`roofline.ceiling`: nominal peak -> power-capped pure-MFMA rate of the kernel's own MFMA shape (live clockbench rows) ->
+    same structure with LDS reads / exponentials / DMA compiled out (committed ablation ratios) -> shipped; pure host arithmetic, checked here"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rows = bench.parse_clockbench_rows("variant   min   median      max  (TFLOP/s over 5 interleaved runs)\n"
+                                       "MFMA only, 2 waves/SIMD                                  1600     1656     1658\n"
+                                       "16x16x32 MFMA only, 2 waves/SIMD                         1911     2000     2004\n"
+                                       "MFMA + 4 VALU + 1 KB LDS (b128+tr mix), 2 w/SIMD         1248     1257     1263\n")
+    assert rows["16x16x32 MFMA only, 2 waves/SIMD"] == 2000 and rows["MFMA only, 2 waves/SIMD"] == 1656
+    c = bench.ceiling_block("c3", "fa_fwd_pp16_kernel", 1260.0, rows)
+    assert c["pure_mfma_on_n01_operands_tflops"]["this_kernels_mfma_shape"] == 2000 and c["frac_of_power_capped_mfma_rate"] == 1260.0 / 2000
+    assert c["chain_tflops"][0][1] == 2500.0 and c["chain_tflops"][-1][1] == 1260.0
+    vals = [v for _, v in c["chain_tflops"]]
+    assert vals == sorted(vals, reverse=True), vals                                   # every step of the chain costs something
+    prod = 1.0
+    for r in c["chain_step_ratios"]:
+        prod *= r
+    assert abs(prod - 1260.0 / 2500.0) < 1e-12
+    if "same_structure_ablated" in c:                                                   # (a committed profiles/rNN_fwd_ceiling_ablations.json exists)
+        assert 0.5 < c["same_structure_ablated"]["time_ratio_vs_shipped"]["no_lds_reads_no_exp_no_dma"] < 1.0
+    assert bench.ceiling_block("c3", "fa_fwd_pp_kernel", 1200.0, rows)["pure_mfma_on_n01_operands_tflops"]["this_kernels_mfma_shape"] == 1656
+    assert bench.ceiling_block("c3", "fa_fwd_pp16_kernel", 1260.0, None)["chain_tflops"][0][1] == 2500.0      # clockbench missing: still a block
+
+
+def _driver_scale_command(n, extra=()):
+    """the driver's SCALE launch, verbatim (task contract): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--fake-step", *extra]
+
+
+def test_driver_scale_command_line_at_eight_ranks():
+    """the first real SCALE run should debut RCCL and nothing else.  bench.py is launched exactly as the driver launches it
+    (torch.distributed.run spawns the ranks and sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; no environment prepared by this test), with the kernels
+    replaced by --fake-step: ONE JSON line on the job's stdout, n_gpus = 8, the headline workload = BASELINE configs[2] per GPU (per-GPU work fixed:
+    `scaling: weak`, global batch 32), configs[4] (b = 32 = 4 per rank, 16k, non-causal) named in `extra`, and at N = 1 the same launcher gives the
+    line a plain `python bench.py` gives (the N = 1 value path does not depend on how it was launched)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run(_driver_scale_command(8), env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["scaling"] == "weak" and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert r["config"]["workload"].startswith("BASELINE configs[2] per GPU: fwd b=4 seq=16384 h=32 h_k=32 d=128 fp16 causal")
+    assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "batch-sharded x8, no collective"
+    assert r["extra"]["c5_weak_noncausal_16k"]["config"] == "BASELINE configs[4] shape: fwd b=32 (4 per rank) seq=16384 h=32 d=128 fp16 non-causal"
+    assert r["units_total"] == 8 * 4 * 32 and r["ms_per_step"] >= 16.0           # MAX over ranks (rank 7 sleeps 2 ms x 8 per fake step)
+    assert r["comm_backend"].startswith("gloo")                                  # (no GPU here: the nccl adoption reports why not)
+    # N = 1: launcher or not, the same line (timing fields aside)
+    one = subprocess.run(_driver_scale_command(1), env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-3000:]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--fake-step"], env=env,
+                           capture_output=True, text=True, timeout=120)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    a, b = (json.loads([l for l in o.stdout.splitlines() if l.startswith("{")][0]) for o in (one, plain))
+    timing = {"value", "ms_per_step", "local_ms", "extra", "comm_backend", "subgroup_collectives"}
+    assert {k: v for k, v in a.items() if k not in timing} == {k: v for k, v in b.items() if k not in timing}
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["config"]["global_batch"] == 4 and "c5_weak_noncausal_16k" not in a["extra"]

@@ -120,10 +120,23 @@ def test_dkdv16_ring_addresses_are_toggled_not_recomputed(kernels):
         if "fa_bwd_dkdv16_kernel" in name:
             seen += 1
             main = max(info["loops"], key=lambda l: l["mfma"])
-            assert main["mfma"] == 64, (name, main["mfma"])
-            assert main["histogram"].get("v_xor_b32", 0) == 13, (name, main["histogram"])              # 4 row + 8 transposed + 1 statistics base
+            d64 = "Li64ELb" in name                                                                     # round 5: the same kernel at head_dim 64
+            assert main["mfma"] == (32 if d64 else 64), (name, main["mfma"])
+            assert main["histogram"].get("v_xor_b32", 0) == (7 if d64 else 13), (name, main["histogram"])      # KS row + DB transposed + 1 statistics base
             assert main["histogram"].get("v_add_u32_e32", 0) <= 14, (name, main["histogram"])
-    assert seen == 4
+    assert seen == 8
+
+
+def test_d64_mfma16_backward_kernels_are_clean(kernels):
+    """round 5: fa_bwd_dq16 / fa_bwd_dkdv16 at head_dim 64 run ONE workgroup per compute unit (160-180 registers; at the 128-register budget of two
+    co-resident workgroups dQ spills 46-86 registers) - they must at least be free of scratch and fit that one workgroup"""
+    seen = 0
+    for (f, name), info in kernels.items():
+        if "Li64ELb" in name and any(k in name for k in ("fa_bwd_dq16_kernel", "fa_bwd_dkdv16_kernel")):
+            seen += 1
+            assert info["occupancy"] >= 2 and info["lds_bytes"] <= 160 * 1024, (name, info["occupancy"], info["lds_bytes"])
+            assert info["scratch_bytes"] == 0, (name, info["scratch_bytes"])
+    assert seen == 8, seen
 
 
 def test_guard_detects_the_known_pathology():

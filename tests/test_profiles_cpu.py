@@ -39,3 +39,27 @@ def test_bench_line_and_profiler_agree_on_the_roofline_fraction():
         assert abs(r["frac"] - b["value"] / r["peak"]) / r["frac"] < 0.01
     assert s["frac_bench_vs_rocprof_relative_difference"] < 0.01, s["frac_bench_vs_rocprof_relative_difference"]
     assert s["library_source_digest"] == r["library_source_digest"]
+
+
+# round-4 run (profiles/r4_mean_rel_table.json): cases whose RAW mean_rel exceeds the reference's plain bound (all under the oracle rule: sk <= 2-type
+# shapes) and cases recorded-not-asserted because the expectation vanishes identically.  VERDICT r4: neither count may grow - a change to tests/_util.py
+# or to a kernel that pushes more cases past the plain bound, or moves cases to the unasserted rule, shows up here.  Test families added later are
+# counted apart (they bring their own small-sk cases); round 5 added the reference's packed-sequence grid.
+OVER_PLAIN_CEILING, ZERO_RULE_CEILING = 955, 932
+FAMILIES_ADDED_AFTER_R4 = {"test_reference_varlen_grid_vs_torch_fp32"}
+
+
+def test_mean_rel_soft_spots_have_not_grown():
+    t = json.load(open(_newest("r*_mean_rel_table.json")))
+    assert t["exit_status"] == 0
+    if "by_family" in t:
+        old = {f: d for f, d in t["by_family"].items() if f not in FAMILIES_ADDED_AFTER_R4}
+        over, zero = sum(d["over_plain_bound"] for d in old.values()), sum(d["zero"] for d in old.values())
+    else:                                                                                # (the round-4 file: totals only)
+        over, zero = len(t["over_plain_bound"]), t["by_rule"]["zero"]["cases"]
+    assert over <= OVER_PLAIN_CEILING, (over, OVER_PLAIN_CEILING)
+    assert zero <= ZERO_RULE_CEILING, (zero, ZERO_RULE_CEILING)
+    # the summary's ratio is of the ASSERTED quantity: a value above 1 would be a failed assertion
+    for rule, d in t["by_rule"].items():
+        if "by_family" in t:
+            assert d["worst_ratio_to_bound"] <= 1.0, (rule, d)

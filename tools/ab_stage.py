@@ -37,6 +37,15 @@ CONFIGS = {
     "bf16 d64 8k causal": (4, 8192, 32, 32, 64, BF16, True),
     "fp16 d64 2k causal": (4, 2048, 32, 32, 64, F16, True),
     "fp16 d128 512 causal": (4, 512, 32, 32, 128, F16, True),
+    "fp16 d64 512": (4, 512, 32, 32, 64, F16, False),
+    "fp16 d64 1k": (4, 1024, 32, 32, 64, F16, False),
+    "bf16 d64 1k": (4, 1024, 32, 32, 64, BF16, False),
+    "bf16 d64 2k": (4, 2048, 32, 32, 64, BF16, False),
+    "fp16 d64 1k causal": (4, 1024, 32, 32, 64, F16, True),
+    "fp16 d64 8k causal b1": (1, 8192, 32, 32, 64, F16, True),
+    "fp16 d64 8k b1": (1, 8192, 32, 32, 64, F16, False),
+    "fp16 d64 4k gqa": (4, 4096, 32, 8, 64, F16, False),
+    "fp16 d64 8k gqa causal": (4, 8192, 32, 8, 64, F16, True),
     "fp16 d64 8k": (4, 8192, 32, 32, 64, F16, False),
     "fp16 d64 2k": (4, 2048, 32, 32, 64, F16, False),
     "fp16 d64 4k": (4, 4096, 32, 32, 64, F16, False),
