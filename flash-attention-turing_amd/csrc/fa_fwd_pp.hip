@@ -567,6 +567,7 @@ constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 22;             // 2048 x 2
 // (profiles/r4_policy_sweep_after_rowsum.log next to profiles/r3_policy_sweep.log; bf16 keeps its VALU row sums and sits within +-2.5 % there).
 constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 24;       // 4096 x 4096
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
+int fwd_pp16_block_m(int d);                                                                          // query rows per workgroup of that kernel
 
 // head_dim 64 (round 4): fp16 through the 16x16x32 kernel with 128-key tiles once its row sums ride the matrix pipe - at head_dim 64 the softmax
 // VALU work per MFMA is twice that of head_dim 128 and the pipe is half idle, so the adds it takes over are worth more: -2 % at 4k, -5 % at 8k / 16k
@@ -594,8 +595,9 @@ const char* fwd_kernel_name_for(const FwdKernelParams& kp, int dtype) { return u
 // fa_fwd_w4.hip: bit-identical to fa_fwd_pp16 and 7-12 % slower - a lone wave cannot issue 16x16x32 MFMAs at the pipe's rate.  Not in the
 // product; profiles/r4_fwd_w4_one_wave_per_simd_ab.log, file in the history.)
 hipError_t launch_fwd(FwdKernelParams kp, int dtype, hipStream_t stream) {
-    kp.n_q_tiles = (uint32_t)((kp.seqlen_q + kFwdBlockM - 1) / kFwdBlockM);
-    kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, kFwdBlockM, kp.n_q_tiles) : 0u;
+    const int block_m = use_mfma16(kp, dtype) ? fwd_pp16_block_m(kp.d) : kFwdBlockM;
+    kp.n_q_tiles = (uint32_t)((kp.seqlen_q + block_m - 1) / block_m);
+    kp.varlen_slots = kp.cu_seqlens_q != nullptr ? varlen_slot_count(kp.total_q, kp.b, block_m, kp.n_q_tiles) : 0u;
     const uint32_t grid = kp.varlen_slots != 0 ? kp.varlen_slots * (uint32_t)kp.h : kp.n_q_tiles * (uint32_t)kp.b * (uint32_t)kp.h;
     // (head_dim 64 runs two workgroups per compute unit except in its 128-key causal shape, launch_pp_t)
     const int wg_per_cu = (kp.d == 64 && !use_mfma16(kp, dtype) && !(FA_FWD_D64_BN != 0 ? FA_FWD_D64_BN == 128 : (kp.is_causal && kp.seqlen_k >= kFwdD64WideMinKeys))) ? 2 : 1;

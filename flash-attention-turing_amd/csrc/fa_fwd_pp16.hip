@@ -22,7 +22,6 @@
 namespace fa {
 
 constexpr int kFwdThreads = 512;
-constexpr int kFwdBlockM = 256;
 constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PP_MIN_WAVES(D, BN) 2
 // FA_PP16_FOLD_MAX (round 3: Q pre-scaled by log2(e)/sqrt(d), score chains started from -running_max; +5 % fp16) was measured and rejected
@@ -83,8 +82,11 @@ constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
 
-template <typename T, int D, bool CAUSAL, int BN>
+// QB = 16-row query columns per wave: 2 (256-row workgroups, the product) or 3 (384 rows; every K / V^T fragment then feeds three MFMAs - a third
+// fewer LDS operand bytes per FLOP - with 32-key tiles so that S / P shrink enough for O (96) + Q (48) to stay at two waves per SIMD; round 5, FA_FWD_D128_QB)
+template <typename T, int D, bool CAUSAL, int BN, int QB = 2>
 __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp16_kernel(const FwdKernelParams p) {
+    constexpr int RW = 16 * QB, kFwdBlockM = 8 * RW;                          // query rows per wave / per workgroup
     constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;      // QK^T k-steps of 32 d; 16-wide d blocks of O
     constexpr int kFwdBlockN = BN, NKB = BN / 16, NC = BN / 32;               // keys per tile; 16-key score blocks / 32-key P.V chunks per tile
     constexpr int TILEB = kFwdBlockN * ROWB;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     //   keys:      row i = 4*gi + r of score block kb is key 16*kb + 4*kPi2[gi] + r   (A = K row i; C rows 4*g + r; P.V k-slots; V^T tr reads)
     const int pi_g = (0x2130 >> (4 * g)) & 3;             // kPi  = {0, 3, 1, 2}
     const int pi2_g = (0x3120 >> (4 * g)) & 3;            // kPi2 = {0, 2, 1, 3}
-    const int q_row_a = wave * 32 + n16;                  // this lane's two query rows inside the 256-row block: q_row_a, q_row_a + 16
+    const int q_row_a = wave * RW + n16;                  // this lane's QB query rows inside the workgroup's block: q_row_a + 16 * qb
     const float c = p.scale_log2e;
     const uint32_t q_rowb = (uint32_t)(p.q.row * 2), k_rowb = (uint32_t)(p.k.row * 2),
                    v_rowb = (uint32_t)(p.v.row * 2), o_rowb = (uint32_t)(p.o.row * 2);
@@ -205,34 +207,36 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         // registers - no Q load, no K / V tile, no LDS, no barrier (round 4: such a workgroup took ~38 us through the full prologue and epilogue, profiles/r4_fwd_dead_rows_ab.log)
         const int rows_here = rows_of(tile);
         const rsrc_t o_rs = make_rsrc(uniform_ptr(o_ptr_of(tile)), (uint32_t)(rows_here - 1) * o_rowb + ROWB);
-        constexpr int O_CHUNKS_DEAD = (32 * SLOTS) / 64;
+        constexpr int O_CHUNKS_DEAD = (RW * SLOTS) / 64;
 #pragma unroll
         for (int i = 0; i < O_CHUNKS_DEAD; ++i) {
-            const int chunk = lane + i * 64, row = wave * 32 + chunk / SLOTS, slot = chunk % SLOTS;
+            const int chunk = lane + i * 64, row = wave * RW + chunk / SLOTS, slot = chunk % SLOTS;
             buf_store16(o_rs, (uint32_t)row * o_rowb + slot * 16, u32x4{0u, 0u, 0u, 0u});      // rows >= rows_here fall outside the SRD
         }
-        if (lane < 32 && wave * 32 + lane < rows_here) lse_bh[tile * kFwdBlockM + wave * 32 + lane] = 0.f;
+        if (lane < RW && wave * RW + lane < rows_here) lse_bh[tile * kFwdBlockM + wave * RW + lane] = 0.f;
         return;
     }
 
     // Q^T fragments (B operand), two query columns per lane: qf[ks][qb] = Q[q_row_a + 16*qb][32*ks + 8*kPi[g] .. +7]
-    u32x4 qf[KS][2];
+    u32x4 qf[KS][QB];
     {
         const rsrc_t q_rs = make_rsrc(uniform_ptr(q_ptr_of(tile)), (uint32_t)(rows_of(tile) - 1) * q_rowb + ROWB);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)(q_row_a + 16 * qb) * q_rowb + (4 * ks + pi_g) * 16);
+            for (int qb = 0; qb < QB; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)(q_row_a + 16 * qb) * q_rowb + (4 * ks + pi_g) * 16);
     }
 
-    f32x4 oacc[DB][2];                                    // O^T: d rows 16*db + 4*g + r, query column qb
+    f32x4 oacc[DB][QB];                                   // O^T: d rows 16*db + 4*g + r, query column qb
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {kNegBig, kNegBig}, l_run[2] = {0.f, 0.f};      // per query column; l_run is this lane's PARTIAL row sum (its 4 of every 16 keys)
+        for (int qb = 0; qb < QB; ++qb) oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QB], l_run[QB];                                      // per query column; l_run is this lane's PARTIAL row sum (its 4 of every 16 keys)
     // ML: l as a 16 x 16 MFMA tile per query column, ones(16 x 32) * P^T: all four registers of every lane hold the column's FULL row sum
-    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 lacc[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = kNegBig; l_run[qb] = 0.f; lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     u32x4 ones_a = {LP<T>::kOnes2, LP<T>::kOnes2, LP<T>::kOnes2, LP<T>::kOnes2};
     if constexpr (ML) asm volatile("" : "+v"(ones_a));           // (a register-resident constant: MFMA operands cannot be literals)
 
@@ -264,9 +268,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     __syncthreads();
     if (group == 1) __syncthreads();          // group B runs one phase behind group A, for the whole life of the workgroup
 
-    f32x4 sacc[NKB][2];                               // S^T: key rows 4*g + r of score block kb (= keys 16*kb + 4*kPi2[g] + r), query column qb
-    u32x4 pf[NC][2];                                  // P^T as B operand of chunk c: k-slots = the lane's 4 keys of block 2c, then of block 2c+1
-    const int wave_q_lo = m0 + wave * 32, wave_q_hi = wave_q_lo + 31;
+    f32x4 sacc[NKB][QB];                              // S^T: key rows 4*g + r of score block kb (= keys 16*kb + 4*kPi2[g] + r), query column qb
+    u32x4 pf[NC][QB];                                 // P^T as B operand of chunk c: k-slots = the lane's 4 keys of block 2c, then of block 2c+1
+    const int wave_q_lo = m0 + wave * RW, wave_q_hi = wave_q_lo + RW - 1;
 
     // One matrix phase = NPV P.V fragments (V(u-1)) + NQK QK^T fragments (K(u)); every fragment feeds TWO MFMAs (the lane's two query columns),
     // so LDS bytes per FLOP are those of the 32x32x16 kernel.  Fragment j + PF is requested before the MFMAs of fragment j.
@@ -290,25 +294,25 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         constexpr int j = decltype(jc)::value;
         if constexpr (j < NPV) {
             constexpr int db = j % DB, cch = j / DB;
-            LP<T>::mfma16_acc(oacc[db][0], fr, pf[cch][0]);          // (this accumulator's previous MFMA is DB fragments = 2 * DB MFMAs back)
-            LP<T>::mfma16_acc(oacc[db][1], fr, pf[cch][1]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(oacc[db][qb], fr, pf[cch][qb]);          // (this accumulator's previous MFMA is DB fragments = QB * DB MFMAs back)
             if constexpr (ML && db == DB - 1) {                      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
                 bool take;
                 if constexpr (std::is_same<decltype(lsc), bool>::value) take = lsc;
                 else take = decltype(lsc)::value;
                 if (take) {
-                    LP<T>::mfma16_acc(lacc[0], ones_a, pf[cch][0]);
-                    LP<T>::mfma16_acc(lacc[1], ones_a, pf[cch][1]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(lacc[qb], ones_a, pf[cch][qb]);
                 }
             }
         } else {
             constexpr int i = j - NPV, ks = i / NKB, kb = i % NKB;
             if constexpr (ks == 0) {                               // (previous MFMA on this accumulator: NKB fragments back)
-                LP<T>::mfma16_zero(sacc[kb][0], fr, qf[ks][0]);
-                LP<T>::mfma16_zero(sacc[kb][1], fr, qf[ks][1]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_zero(sacc[kb][qb], fr, qf[ks][qb]);
             } else {
-                LP<T>::mfma16_acc(sacc[kb][0], fr, qf[ks][0]);
-                LP<T>::mfma16_acc(sacc[kb][1], fr, qf[ks][1]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(sacc[kb][qb], fr, qf[ks][qb]);
             }
         }
     };
@@ -362,12 +366,20 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         // the scores were written by MFMAs issued from inline asm, which the hazard recogniser does not see: a 4-pass XDL write needs its
         // wait states before a VALU reads it (the barrier and the DMA issue in between usually cover them; this makes it unconditional)
         asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+        // ... and the pad has to NAME the registers it protects: its "memory" clobber orders memory operations only, and hipcc is free to schedule a
+        // register-only v_fma / v_exp that reads a score directly behind the MFMA that produces it, above the barrier and this pad (round 5, the 384-row
+        // experiment build: v_fma_f32 two instructions behind its MFMA, P wrong by ~0.1; tests/_mfma_hazards.py walks the ISA of every instance for it).
+        // Volatile asm statements keep their order, so nothing that reads sacc can move above these (no instructions are emitted).
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(sacc[kb][qb]));
         const int n0 = u * kFwdBlockN;
         if constexpr (decltype(masked)::value) {
             const bool need_mask = (n0 + kFwdBlockN > sk) || (CAUSAL && (n0 + kFwdBlockN - 1 > wave_q_lo + delta));
             if (need_mask) {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+                for (int qb = 0; qb < QB; ++qb) {
                     const int lim = (CAUSAL ? min(sk - 1, m0 + q_row_a + 16 * qb + delta) : sk - 1) - n0 - 4 * pi2_g;     // key = n0 + 16*kb + 4*kPi2[g] + r
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb)
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         if constexpr (decltype(maybe_first)::value) {
             if (u == 0) {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+                for (int qb = 0; qb < QB; ++qb) {
                     float mx = sacc[0][qb][0];
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb)
@@ -396,11 +408,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 }
             }
         }
-        float ps[2];
+        float ps[QB];
         // exponentials of the tile against the running max as it stands -> P^T fragments; returns "some P above 2^kPpDeferLog2, or not finite"
         auto pass = [&]() __attribute__((always_inline)) -> bool {
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 const float mc0 = m_run[qb] * c;
                 ps[qb] = 0.f;
 #pragma unroll
@@ -421,7 +433,23 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 // v_pk_maximum3_f16 (IEEE maximum: NaN wins) on bf16 bits is monotone as long as they read as finite fp16, i.e. below 2^121;
                 // anything above, Inf and NaN come out as a pattern above kBits64 as well.
                 uint32_t t0, t1;
-                if constexpr (NC == 2) {
+                if constexpr (QB != 2) {                              // any column count: one chain per query column, merged at the end
+                    uint32_t tq[QB];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        tq[qb] = pk_max3_f16_bits(pf[0][qb].x, pf[0][qb].y, pf[0][qb].z);
+#pragma unroll
+                        for (int cch = 1; cch < NC; ++cch) {
+                            tq[qb] = pk_max3_f16_bits(tq[qb], pf[cch - 1][qb].w, pf[cch][qb].x);
+                            tq[qb] = pk_max3_f16_bits(tq[qb], pf[cch][qb].y, pf[cch][qb].z);
+                        }
+                    }
+                    static_assert(QB == 2 || QB == 3, "guard merge written for three columns");
+                    t0 = pk_max3_f16_bits(tq[0], tq[1], tq[QB - 1]);
+                    t0 = pk_max3_f16_bits(t0, pf[NC - 1][0].w, pf[NC - 1][1].w);
+                    t0 = pk_max3_f16_bits(t0, pf[NC - 1][QB - 1].w, pf[NC - 1][QB - 1].w);
+                    (void)t1;
+                } else if constexpr (NC == 2) {
                     t0 = pk_max3_f16_bits(pf[0][0].x, pf[0][0].y, pf[0][0].z); t1 = pk_max3_f16_bits(pf[0][1].x, pf[0][1].y, pf[0][1].z);
                     t0 = pk_max3_f16_bits(t0, pf[0][0].w, pf[1][0].x); t1 = pk_max3_f16_bits(t1, pf[0][1].w, pf[1][1].x);
                     t0 = pk_max3_f16_bits(t0, pf[1][0].y, pf[1][0].z); t1 = pk_max3_f16_bits(t1, pf[1][1].y, pf[1][1].z);
@@ -441,14 +469,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 const uint32_t both = max(t0, t0 << 16);          // top half = the larger of the two packed values
                 return both > ((LP<T>::kBits64 << 16) | 0xffffu);
             } else {
-                return !(ps[0] <= 64.0f && ps[1] <= 64.0f);
+                bool ok = true;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) ok = ok && ps[qb] <= 64.0f;
+                return !ok;
             }
         };
         if constexpr (MLT) {
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(pass()) != 0, 0)) {
-                float mx[2];
+                float mx[QB];
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+                for (int qb = 0; qb < QB; ++qb) {
                     mx[qb] = sacc[0][qb][0];
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb)
@@ -458,9 +489,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 }
                 // (one decision for both query columns: refreshing a column that did not need it is exact too; a NaN / Inf score fails
                 // both tests and the pass stands with its NaN)
-                if (__builtin_amdgcn_ballot_w64((mx[0] - m_run[0]) * c > kPpDeferLog2 || (mx[1] - m_run[1]) * c > kPpDeferLog2) != 0) {
+                bool grew = false;
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) {
+                for (int qb = 0; qb < QB; ++qb) grew = grew || (mx[qb] - m_run[qb]) * c > kPpDeferLog2;
+                if (__builtin_amdgcn_ballot_w64(grew) != 0) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
                         const float m_new = fmaxf(m_run[qb], mx[qb]);
                         const float alpha = fast_exp2((m_run[qb] - m_new) * c);
                         m_run[qb] = m_new;
@@ -480,9 +514,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         for (int attempt = 0;; ++attempt) {
             const bool over = pass();
             if (attempt != 0 || __builtin_amdgcn_ballot_w64(over) == 0) break;
-            float mx[2];
+            float mx[QB];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 mx[qb] = sacc[0][qb][0];
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
@@ -491,9 +525,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 mx[qb] = max4(mx[qb]);
             }
             // (one decision for both query columns: refreshing a column that did not need it is exact too)
-            if (__builtin_amdgcn_ballot_w64((mx[0] - m_run[0]) * c > kPpDeferLog2 || (mx[1] - m_run[1]) * c > kPpDeferLog2) == 0) break;
+            bool grew = false;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) grew = grew || (mx[qb] - m_run[qb]) * c > kPpDeferLog2;
+            if (__builtin_amdgcn_ballot_w64(grew) == 0) break;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
                 const float m_new = fmaxf(m_run[qb], mx[qb]);
                 const float alpha = fast_exp2((m_run[qb] - m_new) * c);
                 m_run[qb] = m_new;
@@ -508,8 +545,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                     for (int r = 0; r < 4; ++r) oacc[db][qb][r] *= alpha;
             }
         }
-        l_run[0] += ps[0];
-        l_run[1] += ps[1];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) l_run[qb] += ps[qb];
     };
     auto advance_ring = [&]() __attribute__((always_inline)) {
         ring_um1 = ring_u;
@@ -524,10 +561,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");        // (asm-issued MFMAs: results must have landed before the VALU below reads them)
 #pragma unroll
-        for (int db = 0; db < DB; ++db) { asm volatile("" : "+v"(oacc[db][0])); asm volatile("" : "+v"(oacc[db][1])); }
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(oacc[db][qb]));
         const int rows_here = rows_of(t);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
             if constexpr (ML) asm volatile("" : "+v"(lacc[qb]));
             const float l_tot = ML ? sum4(l_run[qb]) + lacc[qb][0] : sum4(l_run[qb]);      // exactly summed tiles + MFMA-summed tiles
             // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
@@ -544,10 +583,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             }
         }
         const rsrc_t o_rs = make_rsrc(uniform_ptr(o_ptr_of(t)), (uint32_t)(rows_here - 1) * o_rowb + ROWB);
-        constexpr int O_CHUNKS = (32 * SLOTS) / 64;
+        constexpr int O_CHUNKS = (RW * SLOTS) / 64;
 #pragma unroll
         for (int i = 0; i < O_CHUNKS; ++i) {
-            const int chunk = lane + i * 64, row = wave * 32 + chunk / SLOTS, slot = chunk % SLOTS;
+            const int chunk = lane + i * 64, row = wave * RW + chunk / SLOTS, slot = chunk % SLOTS;
             buf_store16(o_rs, (uint32_t)row * o_rowb + slot * 16, lds_read16(stage, lds_tile_off<D>(row, slot)));   // rows >= rows_here fall outside the SRD
         }
     };
@@ -700,6 +739,16 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     if (group == 0) __syncthreads();          // group A waits for B's last phase (equal barrier counts)
 }
 
+// FA_FWD_D128_QB / FA_FWD_D128_BN (round 5): the head_dim-128 instance - query columns per wave (2: 256-row workgroups; 3: 384 rows) and keys per tile.
+// The product is 2 / 64; 3 / 32 is the "three query columns" experiment (profiles/r5_fwd_qb3_ab.log), 2 / 32 isolates what the shorter phases cost.
+#ifndef FA_FWD_D128_QB
+#define FA_FWD_D128_QB 2
+#endif
+#ifndef FA_FWD_D128_BN
+#define FA_FWD_D128_BN 64
+#endif
+int fwd_pp16_block_m(int d) { return d == 128 ? 128 * FA_FWD_D128_QB : 256; }      // query rows per workgroup: launch_fwd sizes the grid with it
+
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
     if (kp.d == 64) {      // 128-key tiles: the same 16 KiB tile images, one workgroup per CU
@@ -713,11 +762,11 @@ hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, 
         return hipGetLastError();
     }
     if (dtype == 0) {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, true, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
-        else hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, false, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, true, FA_FWD_D128_BN, FA_FWD_D128_QB>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        else hipLaunchKernelGGL((fa_fwd_pp16_kernel<_Float16, 128, false, FA_FWD_D128_BN, FA_FWD_D128_QB>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
     } else {
-        if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 128, true, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
-        else hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 128, false, 64>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        if (kp.is_causal) hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 128, true, FA_FWD_D128_BN, FA_FWD_D128_QB>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
+        else hipLaunchKernelGGL((fa_fwd_pp16_kernel<__bf16, 128, false, FA_FWD_D128_BN, FA_FWD_D128_QB>), dim3(grid), dim3(kFwdThreads), 0, stream, kp);
     }
     return hipGetLastError();
 }

@@ -13,6 +13,9 @@ PKG = os.path.join(ROOT, "flash-attention-turing_amd")
 sys.path.insert(0, PKG)
 import build as _build  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _mfma_hazards  # noqa: E402
+
 _KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", r"ScratchSize \[bytes/lane\]": "scratch_bytes", r"Occupancy \[waves/SIMD\]": "occupancy",
          r"LDS Size \[bytes/block\]": "lds_bytes"}
 
@@ -67,6 +70,9 @@ def analyse(hip_source, extra_flags=()):
         m = re.search(r"^\.Lfunc_end\d+:", body, re.M)
         body = body[:m.start()] if m else body[:body.rindex("s_endpgm")]
         info["mfma_total"] = len(re.findall(r"v_mfma", body))
+        # results of MFMAs touched before they have landed (tests/_mfma_hazards.py: the asm-issued MFMAs are invisible to hipcc's hazard recogniser)
+        bl = body.split("\n")
+        info["mfma_hazards"] = _mfma_hazards.scan_kernel(bl, 0, len(bl))
         # M0 outside hand-written asm statements (;;#ASMSTART .. ;;#ASMEND): kernels whose LDS-DMA does not save / restore M0 rely on
         # hipcc itself never using it
         outside = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", body, flags=re.S)

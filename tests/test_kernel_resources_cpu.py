@@ -139,6 +139,49 @@ def test_d64_mfma16_backward_kernels_are_clean(kernels):
     assert seen == 8, seen
 
 
+def test_no_instruction_touches_an_mfma_result_before_it_has_landed(kernels):
+    """Round 5: an experiment build of the 16x16x32 forward (three query columns per wave) computed wrong values because hipcc scheduled a v_fma_f32 that
+    reads a score two instructions behind the inline-asm MFMA producing it - above the barrier and the s_nop pad, whose "memory" clobber does not order
+    register-only instructions (profiles/r5_fwd_qb3_ab.log).  Every pad now names its registers; this walks the ISA of every shipped instance."""
+    bad = {k: v["mfma_hazards"][:3] for k, v in kernels.items() if v.get("mfma_hazards")}
+    assert not bad, bad
+
+
+def test_hazard_scan_sees_the_round5_pathology_and_hipccs_own_spacing():
+    from _mfma_hazards import scan_kernel
+
+    racy = """k:
+	v_mfma_f32_16x16x32_f16 v[170:173], v[196:199], v[58:61], v[170:173]
+	v_mfma_f32_16x16x32_f16 v[162:165], v[196:199], v[62:65], v[162:165]
+	s_nop 0
+	v_fma_f32 v208, s40, v170, v187
+	s_barrier
+	s_nop 7
+	v_fma_f32 v209, s40, v162, v187""".split("\n")
+    v = scan_kernel(racy, 0, len(racy))
+    assert len(v) == 1 and "v170" in v[0][1]
+    # what hipcc itself leaves behind a builtin MFMA of either shape (fa_bwd_dq16 / fa_bwd): accepted
+    ok = """k:
+	v_mfma_f32_16x16x32_f16 v[116:119], v[126:129], v[2:5], v[46:49]
+	v_exp_f32_e32 v98, v42
+	v_fma_f32 v42, v44, s2, -v104
+	v_exp_f32_e32 v107, v42
+	v_fma_f32 v42, v45, s2, -v104
+	v_exp_f32_e32 v108, v42
+	s_nop 2
+	v_fma_f32 v42, v116, s2, -v103
+	v_mfma_f32_32x32x16_f16 v[34:49], v[54:57], v[82:85], v[34:49]
+	s_nop 11
+	v_fma_f32 v55, v34, s0, -v118""".split("\n")
+    assert scan_kernel(ok, 0, len(ok)) == []
+    # an AGPR accumulator read one state early
+    early = """k:
+	v_mfma_f32_32x32x16_f16 a[0:15], v[54:57], v[82:85], a[0:15]
+	s_nop 10
+	v_accvgpr_read_b32 v1, a3""".split("\n")
+    assert len(scan_kernel(early, 0, len(early))) == 1
+
+
 def test_guard_detects_the_known_pathology():
     """the detector must fire on the construct it exists for: the wave-level skip branch around asm-accumulator MFMAs"""
     ks = analyse("fa_bwd.hip", extra_flags=["-DFA_TEST_DKDV_SKIP_BRANCH"])
