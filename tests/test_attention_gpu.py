@@ -249,7 +249,17 @@ def test_reference_varlen_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, 
             else:
                 o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(qi, ki, vi, doi, causal)
                 refs = dict(O=o_r[0].cpu().numpy(), dQ=dq_r[0].cpu().numpy(), dK=dk_r[0].cpu().numpy(), dV=dv_r[0].cpu().numpy())
-                lse_r, extra = lse_r[0].cpu(), {t: {} for t in refs}
+                lse_r = lse_r[0].cpu()
+                # (if a plain relative bound fails on a problem this size the C oracle is consulted for that tensor, once per sequence: tests/_util.py "oracle-lazy")
+                lazy = {}
+
+                def oracle_of(t, qi=qi, ki=ki, vi=vi, doi=doi, lazy=lazy):
+                    if not lazy:
+                        o_n, lse_n = A.attn_fwd(n(qi), n(ki), n(vi), causal=causal, round_mode=A.ROUND_FP16)
+                        dq_n, dk_n, dv_n = A.attn_bwd(n(qi), n(ki), n(vi), o_n, lse_n, n(doi), causal=causal, round_mode=A.ROUND_FP16)
+                        lazy.update(O=o_n[0], dQ=dq_n[0], dK=dk_n[0], dV=dv_n[0])
+                    return lazy[t]
+                extra = {t: dict(oracle_fn=(lambda t=t, f=oracle_of: f(t))) for t in refs}
             for got, t in ((o[qs], "O"), (dq[qs], "dQ"), (dk[ks], "dK"), (dv[ks], "dV")):
                 U.assert_close(n(got), refs[t], "fp16", f"{t} {tag}", sk=int(lk[i]), **extra[t])
             assert (lse[i, :, : lq[i]].cpu() - lse_r).abs().max().item() <= U.LSE_TOL, "LSE " + tag

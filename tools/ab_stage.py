@@ -87,10 +87,15 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="")
     ap.add_argument("--stages", default="fwd,dq,dkdv")
+    ap.add_argument("--policy", type=int, default=None, help="fa_set_kernel_policy on every build that has it (0 = 32x32x16 set, 1 = 16x16x32 set, 2 = by size)")
     ap.add_argument("--no-workspace", action="store_true", help="do not give ABI 3 builds the dK/dV scratch (single-pass dK/dV)")
     a = ap.parse_args()
     libs = {f"{chr(65 + i)}:{os.path.basename(p)[6:-3]}": load(p) for i, p in enumerate(a.libs)}
     stages = a.stages.split(",")
+    if a.policy is not None:
+        for L in libs.values():
+            if hasattr(L, "fa_set_kernel_policy"):
+                L.fa_set_kernel_policy(a.policy)
     dev = torch.device("cuda:0")
     for cname, cfg in CONFIGS.items():
         if a.only and not any(x in cname for x in a.only.split(",")):
