@@ -31,9 +31,8 @@ namespace fa {
 #ifndef FA_KV16_DMA_EARLY
 #define FA_KV16_DMA_EARLY 0   // which q-half group requests the next tile at the top of the loop (the other one after its S / dP MFMAs); 2 = both at the top
 #endif
-#ifndef FA_KV16_DMA_SPREAD
-#define FA_KV16_DMA_SPREAD 0  // (round 5) 1 = the wave's four pieces of the next tile go out ONE BY ONE behind the MFMAs of the four S / dP k-steps instead of back to back
-#endif                        // (a vector-memory instruction costs its wave ~100 cycles of issue here; between MFMAs that time is the matrix pipe's, not the wave's)
+// (Round 5, measured and not kept - code in the history at 1ef1631: FA_KV16_DMA_SPREAD, the four pieces issued one by one between the MFMAs of the S / dP k-steps
+// (+1.5..6 %) or of the dV / dK fragment steps (+5..23 %) instead of back to back, profiles/r5_bwd_dkdv_dma_spread_ab.log.)
 #ifndef FA_KV16_STAT_PRED
 #define FA_KV16_STAT_PRED(CAUSAL) (!(CAUSAL))   // the per-tile statistics load under an EXEC mask in the six waves that do not use it: the non-causal instances only
 #endif
@@ -211,13 +210,6 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
             dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
         }
     };
-    // one piece of the next tile (n = 0 .. 2 * PPW_Q - 1: Q pieces first, then dO), for FA_KV16_DMA_SPREAD
-    [[maybe_unused]] auto issue_piece = [&](int buf, int n) {
-        const uint32_t m0 = (uint32_t)pf_m0();
-        const int i = n % PPW_Q, piece = wave * PPW_Q + i;
-        if (n < PPW_Q) dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(q_srd, q_src[i] + m0 * q_rowb, lds0 + OFF_Q + buf * TILEB + piece * 1024);
-        else dma16_to_lds_hidden<FA_BWD_DMA_SAVE_M0 != 0>(do_srd, do_src[i] + m0 * do_rowb, lds0 + OFF_DO + buf * TILEB + piece * 1024);
-    };
     const float st_mult = wave == 0 ? -kLog2e : -1.0f;
     auto load_stat = [&](bool valid) -> float {
         const uint32_t off = valid ? ((uint32_t)pf_m0() + (uint32_t)lane) * 4u : 0xfffffff0u;
@@ -283,7 +275,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
         FA_LDS char* sbuf = stat + buf * STATB;
 #endif
         const bool more = (it + 1 < n_iters);
-#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1 && !FA_KV16_DMA_SPREAD
+#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
         if (more && (FA_KV16_DMA_EARLY == 2 || qh == FA_KV16_DMA_EARLY)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
 #endif
         // Only the two statistics waves need this load, and a vector-memory instruction costs its wave ~100 cycles whatever it returns.  A LANE-dependent condition
@@ -341,21 +333,14 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
                         sacc[i][kc] = LP<T>::mfma16(qa[i], kreg[ks][kc], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[i][kc]);      // S = Q K^T
                         dpacc[i][kc] = LP<T>::mfma16(da[i], vf[kc], ks == 0 ? nd4[i] : dpacc[i][kc]);                              // dP - D = dO V^T - D
                     }
-#if FA_KV16_DMA_SPREAD == 1 && !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
-                // ring slot buf^1 was last read in iteration it-1: any point of this iteration is safe
-                if (more) {
-#pragma unroll
-                    for (int n = ks * (2 * PPW_Q) / KS; n < (ks + 1) * (2 * PPW_Q) / KS; ++n) issue_piece(buf ^ 1, n);
-                }
-#endif
             }
 #if FA_KV16_DMA_DEBUG == 2
             if (more && qh == 1) asm volatile("s_sleep 64" ::: "memory");
 #endif
-#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1 && !FA_KV16_DMA_SPREAD
+#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
             if (more && FA_KV16_DMA_EARLY != 2 && qh == (FA_KV16_DMA_EARLY ^ 1)) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
 #endif
-#if FA_KV16_DMA_DEBUG != 1 && FA_KV16_DMA_SPREAD != 2
+#if FA_KV16_DMA_DEBUG != 1
             if (more) pf_advance();
 #endif
 #pragma unroll
@@ -426,17 +411,11 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
                 const int db = j >> 1;
                 if (j & 1) { LP16<T>::mfma_agpr(dkacc[db][0], frag[j], dsfr[0]); LP16<T>::mfma_agpr(dkacc[db][1], frag[j], dsfr[1]); }      // dK^T += Q^T dS
                 else { LP16<T>::mfma_agpr(dvacc[db][0], frag[j], pfr[0]); LP16<T>::mfma_agpr(dvacc[db][1], frag[j], pfr[1]); }              // dV^T += dO^T P
-#if FA_KV16_DMA_SPREAD == 2 && !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
-                // (2 = the same, in the FIRST HALF of the dV / dK phase: every second fragment step; the asm MFMAs and the scheduling fences pin the placement)
-                if (more && j < 4 * PPW_Q && (j & 1)) issue_piece(buf ^ 1, j >> 1);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #if FA_KV16_DMA_DEBUG == 1
         if (more) { issue_tile(buf ^ 1); pf_advance(); }
-#elif FA_KV16_DMA_SPREAD == 2
-        if (more) pf_advance();
 #endif
 #if !(FA_KV16_ABL & 32)
         if (more && wave < 2) store_stat(st_next, buf ^ 1);

@@ -78,13 +78,8 @@ constexpr float kPpDeferLog2 = 6.0f;
 #if FA_PP16_RACY && FA_PP16_ROLE_DMA
 #error "FA_PP16_RACY is the symmetric-role form: build with -DFA_PP16_ROLE_DMA=0"
 #endif
-// FA_PP16_FOLD_ROWS (round 5): under a causal mask wave w owns the 16-row blocks w and 15 - w of the workgroup's 256 rows instead of 2w and 2w + 1, and a
-// query column whose rows see no key of a diagonal tile skips its MFMAs there.  With contiguous rows the four diagonal tiles cost four tile-times (wave 7
-// works through all of them, wave 0 through one, everybody meets at the barriers); folded, every wave carries 5 column-tiles and the slowest wave of the
-// tiles does 2 + 2 + 1 + 1 columns: three tile-times.  Rows are independent and each keeps its own tile order, so the bits do not change.
-#ifndef FA_PP16_FOLD_ROWS
-#define FA_PP16_FOLD_ROWS 0
-#endif
+// (Round 5, measured and not kept - code in the history at 1ef1631: FA_PP16_FOLD_ROWS, wave w owning the 16-row blocks w and 15 - w under a causal mask with per-column
+// MFMA skipping on the diagonal: +0.6 % at 16k, +3..9 % below - the masked tiles are LDS / VALU bound and every wave then runs all four, profiles/r5_fwd_fold_rows_ab.log.)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
@@ -115,10 +110,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     //   keys:      row i = 4*gi + r of score block kb is key 16*kb + 4*kPi2[gi] + r   (A = K row i; C rows 4*g + r; P.V k-slots; V^T tr reads)
     const int pi_g = (0x2130 >> (4 * g)) & 3;             // kPi  = {0, 3, 1, 2}
     const int pi2_g = (0x3120 >> (4 * g)) & 3;            // kPi2 = {0, 2, 1, 3}
-    constexpr bool FOLD = CAUSAL && QB == 2 && FA_PP16_FOLD_ROWS != 0;
-    int q_row[QB];                                        // this lane's QB query rows inside the workgroup's block (one per query column)
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) q_row[qb] = 16 * (FOLD ? (qb == 0 ? wave : 15 - wave) : QB * wave + qb) + n16;
+    const int q_row_a = wave * RW + n16;                  // this lane's QB query rows inside the workgroup's block: q_row_a + 16 * qb
     const float c = p.scale_log2e;
     const uint32_t q_rowb = (uint32_t)(p.q.row * 2), k_rowb = (uint32_t)(p.k.row * 2),
                    v_rowb = (uint32_t)(p.v.row * 2), o_rowb = (uint32_t)(p.o.row * 2);
@@ -234,7 +226,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)q_row[qb] * q_rowb + (4 * ks + pi_g) * 16);
+            for (int qb = 0; qb < QB; ++qb) qf[ks][qb] = buf_load16(q_rs, (uint32_t)(q_row_a + 16 * qb) * q_rowb + (4 * ks + pi_g) * 16);
     }
 
     f32x4 oacc[DB][QB];                                   // O^T: d rows 16*db + 4*g + r, query column qb
@@ -280,9 +272,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     f32x4 sacc[NKB][QB];                              // S^T: key rows 4*g + r of score block kb (= keys 16*kb + 4*kPi2[g] + r), query column qb
     u32x4 pf[NC][QB];                                 // P^T as B operand of chunk c: k-slots = the lane's 4 keys of block 2c, then of block 2c+1
-    // first / last query row of the wave (folded: block w .. block 15 - w) and the last row of its first column
-    const int wave_q_lo = m0 + (FOLD ? 16 * wave : wave * RW), wave_q_hi = FOLD ? m0 + 16 * (15 - wave) + 15 : wave_q_lo + RW - 1;
-    [[maybe_unused]] const int col0_q_hi = m0 + 16 * wave + 15;
+    const int wave_q_lo = m0 + wave * RW, wave_q_hi = wave_q_lo + RW - 1;
 
     // One matrix phase = NPV P.V fragments (V(u-1)) + NQK QK^T fragments (K(u)); every fragment feeds TWO MFMAs (the lane's two query columns),
     // so LDS bytes per FLOP are those of the 32x32x16 kernel.  Fragment j + PF is requested before the MFMAs of fragment j.
@@ -302,18 +292,12 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     };
     // `lsc`: the pending P tile was produced by the MFMA-sum path -> its row sums are taken here (compile-time yes / no, or a run-time bool)
     bool prev_ml = false;
-    // `c0`: does query column 0 take part (a compile-time yes in the steady loop; the folded diagonal passes a wave-uniform bool)
-    auto m_mfma = [&](auto jc, const u32x4& fr, auto lsc, auto c0) __attribute__((always_inline)) {
+    auto m_mfma = [&](auto jc, const u32x4& fr, auto lsc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        auto col = [&](int qb) __attribute__((always_inline)) -> bool {
-            if constexpr (std::is_same<decltype(c0), bool>::value) return qb != 0 || c0;
-            else return true;
-        };
         if constexpr (j < NPV) {
             constexpr int db = j % DB, cch = j / DB;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-                if (col(qb)) LP<T>::mfma16_acc(oacc[db][qb], fr, pf[cch][qb]);          // (this accumulator's previous MFMA is DB fragments = QB * DB MFMAs back)
+            for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(oacc[db][qb], fr, pf[cch][qb]);          // (this accumulator's previous MFMA is DB fragments = QB * DB MFMAs back)
             if constexpr (ML && db == DB - 1) {                      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
                 bool take;
                 if constexpr (std::is_same<decltype(lsc), bool>::value) take = lsc;
@@ -327,12 +311,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             constexpr int i = j - NPV, ks = i / NKB, kb = i % NKB;
             if constexpr (ks == 0) {                               // (previous MFMA on this accumulator: NKB fragments back)
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    if (col(qb)) LP<T>::mfma16_zero(sacc[kb][qb], fr, qf[ks][qb]);
+                for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_zero(sacc[kb][qb], fr, qf[ks][qb]);
             } else {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    if (col(qb)) LP<T>::mfma16_acc(sacc[kb][qb], fr, qf[ks][qb]);
+                for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(sacc[kb][qb], fr, qf[ks][qb]);
             }
         }
     };
@@ -346,7 +328,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             constexpr int j = decltype(jc)::value;
             if constexpr (j + PF < NST) fr[j + PF] = m_frag(j + PF, slot_v, slot_k);
             __builtin_amdgcn_sched_barrier(0);
-            m_mfma(jc, fr[j], lsc, std::integral_constant<bool, true>{});
+            m_mfma(jc, fr[j], lsc);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -355,15 +337,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         for (int j = 0; j < PF; ++j) pre[j] = m_frag(j, slot_v, slot_k);
     };
     // un-pipelined halves for the first / diagonal / last tiles
-    // (`c0`: FOLD only - query column 0 has a pending P / sees a key of this tile; a skipped column's scores are never read: the mask select
-    // of softmax_step overwrites them with -inf, its P is 0 and its P.V is skipped in turn)
-    auto pv_step = [&](bool c0) __attribute__((always_inline)) {
-        if constexpr (FOLD) static_for<0, NPV>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), prev_ml, c0); });
-        else static_for<0, NPV>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), prev_ml, std::integral_constant<bool, true>{}); });
+    auto pv_step = [&]() __attribute__((always_inline)) {
+        static_for<0, NPV>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), prev_ml); });
     };
-    auto qk_step = [&](bool c0) __attribute__((always_inline)) {
-        if constexpr (FOLD) static_for<NPV, NST>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), false, c0); });
-        else static_for<NPV, NST>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), false, std::integral_constant<bool, true>{}); });
+    auto qk_step = [&]() __attribute__((always_inline)) {
+        static_for<NPV, NST>([&](auto jc) { m_mfma(jc, m_frag(decltype(jc)::value, ring_um1, ring_u), false); });
     };
     auto issue_dma_k = [&](int u) __attribute__((always_inline)) {
         if (u + 2 < n_tiles) dma_k_tile(k_srd, u + 2, ring_um1);
@@ -404,7 +382,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             if (need_mask) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    const int lim = (CAUSAL ? min(sk - 1, m0 + q_row[qb] + delta) : sk - 1) - n0 - 4 * pi2_g;     // key = n0 + 16*kb + 4*kPi2[g] + r
+                    const int lim = (CAUSAL ? min(sk - 1, m0 + q_row_a + 16 * qb + delta) : sk - 1) - n0 - 4 * pi2_g;     // key = n0 + 16*kb + 4*kPi2[g] + r
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -596,7 +574,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             // dead rows (row sum exactly 0): O = 0, LSE = 0; a NaN row sum is NOT dead, it propagates (flash_fwd_kernel.h:718,767: `!= 0`)
             const float inv = l_tot != 0.f ? fast_rcp(l_tot) : 0.f;
             const float lse = l_tot != 0.f ? (m_run[qb] * c + fast_log2(l_tot)) * kLn2 : 0.f;
-            const int row = q_row[qb];
+            const int row = q_row_a + 16 * qb;
             if (g == 0 && row < rows_here) lse_bh[t * kFwdBlockM + row] = lse;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -610,8 +588,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         constexpr int O_CHUNKS = (RW * SLOTS) / 64;
 #pragma unroll
         for (int i = 0; i < O_CHUNKS; ++i) {
-            const int chunk = lane + i * 64, rl = chunk / SLOTS, slot = chunk % SLOTS;      // rl: row inside the wave's RW rows
-            const int row = FOLD ? 16 * ((rl >> 4) == 0 ? wave : 15 - wave) + (rl & 15) : wave * RW + rl;
+            const int chunk = lane + i * 64, row = wave * RW + chunk / SLOTS, slot = chunk % SLOTS;
             buf_store16(o_rs, (uint32_t)row * o_rowb + slot * 16, lds_read16(stage, lds_tile_off<D>(row, slot)));   // rows >= rows_here fall outside the SRD
         }
     };
@@ -619,16 +596,11 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     using no = std::integral_constant<bool, false>;
 
     bool prev_active = false;                         // does this wave hold a P tile whose P.V is pending?
-    bool prev_c0 = true;                              // ... with a non-zero column 0?
     auto iteration = [&](int u, auto masked) __attribute__((always_inline)) {
-        bool active = true, c0 = true;
-        if constexpr (decltype(masked)::value) {
-            active = !CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta);
-            if constexpr (FOLD) c0 = u * kFwdBlockN <= col0_q_hi + delta;
-        }
-        if (prev_active) pv_step(prev_c0);
-        if (active) qk_step(c0);
-        prev_c0 = c0;
+        bool active = true;
+        if constexpr (decltype(masked)::value) active = !CAUSAL || (u * kFwdBlockN <= wave_q_hi + delta);
+        if (prev_active) pv_step();
+        if (active) qk_step();
         issue_dma_k(u);
         __syncthreads();
         issue_dma_v(u);
@@ -764,7 +736,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         }
     }
     for (; u < n_tiles; ++u) iteration(u, yes{});        // diagonal / ragged tiles
-    if (prev_active) pv_step(prev_c0);
+    if (prev_active) pv_step();
     epilogue(tile);
     if (group == 0) __syncthreads();          // group A waits for B's last phase (equal barrier counts)
 }
