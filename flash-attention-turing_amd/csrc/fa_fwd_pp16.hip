@@ -49,6 +49,10 @@ constexpr float kPpDeferLog2 = 6.0f;
 // is first read in A's M(u+2), and V(u+2) requested in B's S(u) is first touched by group A's prefetch at the end of A's S(u+2): both can stay in
 // flight for a whole tile period and are retired by a COUNTED wait at the end of the requesting group's NEXT softmax phase (step_c).  Requests
 // are unconditional there (a tile past the sequence's end is a zero fill, one past the mask's end is fetched and never read).
+// Invariants behind "unconditional" (ADVICE r4): (1) a ring slot that received a tile >= n_tiles is never read - the loops stop at n_tiles and the slot's next tenant
+// is written before its first read; (2) the 32-bit source offset (t * BN) * row_bytes cannot wrap back into the descriptor's range: the loop runs only with
+// n_main >= 4, i.e. seqlen_k >= 4 * BN, and the C-ABI refuses a sequence that spans 2^31 bytes (fa_capi.hip:check_tensor), so (seqlen_k + 2 * BN) * row_bytes
+// <= 1.5 * seqlen_k * row_bytes < 2^32 and a request two tiles past the end lands beyond num_records (zero fill), never below it.
 #ifndef FA_PP16_ROLE_DMA
 #define FA_PP16_ROLE_DMA 1
 #endif
