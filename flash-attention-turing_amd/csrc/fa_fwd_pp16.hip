@@ -56,6 +56,12 @@ constexpr float kPpDeferLog2 = 6.0f;
 #ifndef FA_PP16_ROLE_DMA
 #define FA_PP16_ROLE_DMA 1
 #endif
+// FA_PP16_ROWSUM_IN_S (round 5): the row-sum MFMAs of a tile are issued by the wave that has just finished the tile's softmax, at the END of its softmax phase,
+// instead of riding in its next matrix phase.  A lone wave issues v_mfma_f32_16x16x32 every ~18.8 cycles against the pipe's 16 (tools/ubench), so the matrix
+// phase is bound by its wave's issue and leaves ~15 % of the pipe free: four MFMAs from the partner wave fit into that, and the matrix phase is four issues shorter.
+#ifndef FA_PP16_ROWSUM_IN_S
+#define FA_PP16_ROWSUM_IN_S 0
+#endif
 #ifndef FA_PP16_EXACT_TILES
 #define FA_PP16_EXACT_TILES 16
 #endif
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             constexpr int db = j % DB, cch = j / DB;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(oacc[db][qb], fr, pf[cch][qb]);          // (this accumulator's previous MFMA is DB fragments = QB * DB MFMAs back)
-            if constexpr (ML && db == DB - 1) {                      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
+            if constexpr (ML && db == DB - 1 && !FA_PP16_ROWSUM_IN_S) {      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
                 bool take;
                 if constexpr (std::is_same<decltype(lsc), bool>::value) take = lsc;
                 else take = decltype(lsc)::value;
@@ -333,6 +339,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             if constexpr (j + PF < NST) fr[j + PF] = m_frag(j + PF, slot_v, slot_k);
             __builtin_amdgcn_sched_barrier(0);
             m_mfma(jc, fr[j], lsc);
+#if FA_PP16_ABL & 32
+            if constexpr (!std::is_same<decltype(lsc), bool>::value) {
+                if constexpr (decltype(lsc)::value && j < DB) {      // (timing only: two scores per query column behind each of the first DB fragment steps)
+                    constexpr int kb = NKB / 2 + j / 4, r0 = (j % 4) & 2, qb = j & 1;
+                    const float e0 = fast_exp2(__builtin_fmaf(sacc[kb][qb][r0], c, -m_run[qb] * c));
+                    const float e1 = fast_exp2(__builtin_fmaf(sacc[kb][qb][r0 + 1], c, -m_run[qb] * c));
+                    const uint32_t w = LP<T>::pack2(e0, e1);
+                    asm volatile("" ::"v"(w));
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -423,6 +440,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                 ps[qb] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
+#if FA_PP16_ABL & 16
+                    if (MLT && kb >= NKB / 2) continue;      // (timing only: the second half of the tile's exponentials is not computed here)
+#endif
 #if FA_PP16_ABL & 4
                     const float p0 = sacc[kb][qb][0] * 0.01f + mc0 * 0.f, p1 = sacc[kb][qb][1] * 0.01f, p2 = sacc[kb][qb][2] * 0.01f, p3 = sacc[kb][qb][3] * 0.01f;
 #else
@@ -515,6 +535,22 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                     (void)pass();
                 }
             }
+#if FA_PP16_ROWSUM_IN_S
+            // the tile's row sums, now: ones(16 x 32) * P^T per 32-key chunk and query column (P was written by v_cvt_pk a moment ago: VALU -> MFMA source hazard)
+#pragma unroll
+            for (int cch = 0; cch < NC; ++cch)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(pf[cch][qb]));
+            asm volatile("s_nop 1" ::: "memory");      // (volatile statements keep their order: every P register is final before the pad and named again behind it)
+#pragma unroll
+            for (int cch = 0; cch < NC; ++cch)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(pf[cch][qb]));
+#pragma unroll
+            for (int cch = 0; cch < NC; ++cch)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(lacc[qb], ones_a, pf[cch][qb]);
+#endif
             return;
         }
         for (int attempt = 0;; ++attempt) {
