@@ -56,12 +56,8 @@ constexpr float kPpDeferLog2 = 6.0f;
 #ifndef FA_PP16_ROLE_DMA
 #define FA_PP16_ROLE_DMA 1
 #endif
-// FA_PP16_ROWSUM_IN_S (round 5): the row-sum MFMAs of a tile are issued by the wave that has just finished the tile's softmax, at the END of its softmax phase,
-// instead of riding in its next matrix phase.  A lone wave issues v_mfma_f32_16x16x32 every ~18.8 cycles against the pipe's 16 (tools/ubench), so the matrix
-// phase is bound by its wave's issue and leaves ~15 % of the pipe free: four MFMAs from the partner wave fit into that, and the matrix phase is four issues shorter.
-#ifndef FA_PP16_ROWSUM_IN_S
-#define FA_PP16_ROWSUM_IN_S 0
-#endif
+// (Round 5, measured and not kept - code in the history at d4db12e: FA_PP16_ROWSUM_IN_S, the tile's row-sum MFMAs issued at the end of the softmax phase instead of riding
+// in the wave's next matrix phase: bit-identical, +-0.3 %, profiles/r5_fwd_phase_balance_ablations.log.)
 #ifndef FA_PP16_EXACT_TILES
 #define FA_PP16_EXACT_TILES 16
 #endif
@@ -70,7 +66,8 @@ constexpr float kPpDeferLog2 = 6.0f;
 #endif
 #ifndef FA_PP16_ABL
 #define FA_PP16_ABL 0       // timing-only ablations (results WRONG), bit mask: 1 the steady loop does not wait for its LDS-DMA, 2 does not issue it, 4 no exponentials (one multiply
-#endif                      // per score instead of fma + exp), 8 no LDS fragment reads in the matrix phases (profiles/r4_fwd_pp16_ablations.log)
+#endif                      // per score instead of fma + exp), 8 no LDS fragment reads in the matrix phases (profiles/r4_fwd_pp16_ablations.log), 16 the softmax phase skips the second half of the
+                            // tile's exponentials, 32 the next matrix phase carries them as extra work (profiles/r5_fwd_phase_balance_ablations.log)
 // FA_PP16_DMA_DEBUG (round 5; test builds only, the product is 0 and its ISA does not change): adversarial timing for the LDS-DMA protocol of the
 // unrolled steady loop.  A race of the class "a consumer reads a ring slot before the wait + barrier that publishes the producer's pieces" is invisible
 // to every value test as long as the DMA is usually early (profiles/r4_fwd_counted_wait_racy_form_ab.log was bit-identical on every shape and wrong).
@@ -308,7 +305,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             constexpr int db = j % DB, cch = j / DB;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(oacc[db][qb], fr, pf[cch][qb]);          // (this accumulator's previous MFMA is DB fragments = QB * DB MFMAs back)
-            if constexpr (ML && db == DB - 1 && !FA_PP16_ROWSUM_IN_S) {      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
+            if constexpr (ML && db == DB - 1) {                      // the chunk's row sums (previous MFMA on lacc: a whole chunk back)
                 bool take;
                 if constexpr (std::is_same<decltype(lsc), bool>::value) take = lsc;
                 else take = decltype(lsc)::value;
@@ -535,22 +532,6 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
                     (void)pass();
                 }
             }
-#if FA_PP16_ROWSUM_IN_S
-            // the tile's row sums, now: ones(16 x 32) * P^T per 32-key chunk and query column (P was written by v_cvt_pk a moment ago: VALU -> MFMA source hazard)
-#pragma unroll
-            for (int cch = 0; cch < NC; ++cch)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(pf[cch][qb]));
-            asm volatile("s_nop 1" ::: "memory");      // (volatile statements keep their order: every P register is final before the pad and named again behind it)
-#pragma unroll
-            for (int cch = 0; cch < NC; ++cch)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(pf[cch][qb]));
-#pragma unroll
-            for (int cch = 0; cch < NC; ++cch)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) LP<T>::mfma16_acc(lacc[qb], ones_a, pf[cch][qb]);
-#endif
             return;
         }
         for (int attempt = 0;; ++attempt) {
