@@ -147,6 +147,18 @@ def test_no_instruction_touches_an_mfma_result_before_it_has_landed(kernels):
     assert not bad, bad
 
 
+def test_three_query_column_experiment_build_stays_buildable_and_hazard_free():
+    """The switches of the round-5 experiment stay in the source (FA_FWD_D128_QB / FA_FWD_D128_BN, profiles/r5_fwd_qb3_ab.log): the build they select must keep
+    compiling at two waves per SIMD inside 160 KiB of LDS, without scratch in its MFMA loops, and - it is the build the hazard was found in - without a finding."""
+    ks = {n: i for n, i in analyse("fa_fwd_pp16.hip", extra_flags=["-DFA_FWD_D128_QB=3", "-DFA_FWD_D128_BN=32"]).items() if "Li128ELb" in n and "Li32ELi3E" in n}
+    assert len(ks) == 4, list(ks)
+    for name, info in ks.items():
+        assert info["occupancy"] >= 2 and info["lds_bytes"] <= 160 * 1024, (name, info["occupancy"], info["lds_bytes"])
+        assert info["scratch_bytes"] <= 32, (name, info["scratch_bytes"])          # (fp16 causal: four registers stored before the loops, reloaded behind them)
+        assert all(l["scratch_ops"] == 0 for l in info["loops"]), name
+        assert info["mfma_hazards"] == [], (name, info["mfma_hazards"][:3])
+
+
 def test_hazard_scan_sees_the_round5_pathology_and_hipccs_own_spacing():
     from _mfma_hazards import scan_kernel
 
