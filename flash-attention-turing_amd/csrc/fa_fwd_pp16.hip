@@ -87,6 +87,14 @@ constexpr float kPpDeferLog2 = 6.0f;
 #endif
 // (Round 5, measured and not kept - code in the history at 1ef1631: FA_PP16_FOLD_ROWS, wave w owning the 16-row blocks w and 15 - w under a causal mask with per-column
 // MFMA skipping on the diagonal: +0.6 % at 16k, +3..9 % below - the masked tiles are LDS / VALU bound and every wave then runs all four, profiles/r5_fwd_fold_rows_ab.log.)
+#ifndef FA_PP16_DMA_FUSED
+#define FA_PP16_DMA_FUSED 1    // (round 5) the four role pieces of a tile as one statement (fa_device.hpp:dma16x4_to_lds_hidden)
+#endif
+#ifndef FA_PP16_SKIP_PAD
+#define FA_PP16_SKIP_PAD 1     // (round 5) the steady loop's softmax phase drops its wait-state pad when the fused DMA statement stands in front of it
+#endif
+// (Round 5, measured and not kept: a bare s_barrier instead of __syncthreads() at the end of the steady loop's softmax phase, so that hipcc does not wait (lgkmcnt(0)) for the
+// fragments m_prefetch has just requested - bit-identical, no gain on top of the two switches above: the wave waits at that barrier anyway, profiles/r5_fwd_sphase_trim_ab.log.)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
@@ -263,7 +271,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     const srd_t r_srd = group ? v_srd : k_srd;
     auto dma_role_tile = [&](int t, int slot) __attribute__((always_inline)) {      // group A: K(t), group B: V(t)
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) dma16_to_lds_hidden<false>(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb + dma_goff_r[i], lds_r0 + slot * TILEB + i * 1024);
+        for (int i = 0; i < (FA_PP16_DMA_FUSED && RPW == 4 ? 0 : RPW); ++i) dma16_to_lds_hidden<false>(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb + dma_goff_r[i], lds_r0 + slot * TILEB + i * 1024);
+#if FA_PP16_DMA_FUSED
+        if constexpr (RPW == 4) dma16x4_to_lds_hidden(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb, dma_goff_r[0], dma_goff_r[1], dma_goff_r[2], dma_goff_r[3], lds_r0 + slot * TILEB);
+#endif
     };
 #endif
 
@@ -381,11 +392,13 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         return sum_both_halves(x);
     };
     // `mlc`: this tile's row sums go through the matrix pipe (no VALU adds, packed-max guard) / stay exact in the VALU
-    auto softmax_step = [&](int u, auto masked, auto maybe_first, auto mlc) __attribute__((always_inline)) {
+    // `covered`: the caller has put >= 8 wait states of its own between the tile's last MFMA and this call (the steady loop: barrier + the fused DMA statement,
+    // 18 of them) - the pad is then dropped, the register ties below stay (round 5; tests/_mfma_hazards.py counts the states in every instance's ISA)
+    auto softmax_step = [&](int u, auto masked, auto maybe_first, auto mlc, auto covered) __attribute__((always_inline)) {
         constexpr bool MLT = ML && decltype(mlc)::value;
         // the scores were written by MFMAs issued from inline asm, which the hazard recogniser does not see: a 4-pass XDL write needs its
         // wait states before a VALU reads it (the barrier and the DMA issue in between usually cover them; this makes it unconditional)
-        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+        if constexpr (!decltype(covered)::value) asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
         // ... and the pad has to NAME the registers it protects: its "memory" clobber orders memory operations only, and hipcc is free to schedule a
         // register-only v_fma / v_exp that reads a score directly behind the MFMA that produces it, above the barrier and this pad (round 5, the 384-row
         // experiment build: v_fma_f32 two instructions behind its MFMA, P wrong by ~0.1; tests/_mfma_hazards.py walks the ISA of every instance for it).
@@ -625,7 +638,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         issue_dma_k(u);
         __syncthreads();
         issue_dma_v(u);
-        if (active) softmax_step(u, masked, yes{}, no{});      // exact row sums in every masked / first tile
+        if (active) softmax_step(u, masked, yes{}, no{}, no{});      // exact row sums in every masked / first tile
         prev_active = active;
         prev_ml = false;
         end_s_phase();
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             // Retired: the tile requested one softmax phase ago (K(u+1) / V(u+1)), by count - this phase's four pieces stay in flight.
 #if FA_PP16_DMA_DEBUG == 1
             // LATE ISSUE: the request the counted wait of this phase would retire (tile u+1, made one phase ago in the product) goes out here instead
-            softmax_step(uu, no{}, no{}, mlc);
+            softmax_step(uu, no{}, no{}, mlc, no{});
             m_prefetch(S_U, S_UP1);
             dma_role_tile(uu + 1, S_UP1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #if !(FA_PP16_ABL & 2)
             dma_role_tile(uu + 2, S_UM1);
 #endif
-            softmax_step(uu, no{}, no{}, mlc);
+            softmax_step(uu, no{}, no{}, mlc, std::integral_constant<bool, FA_PP16_DMA_FUSED && !(FA_PP16_ABL & 2) && FA_PP16_SKIP_PAD && (BN * (D / 8) / 256 == 4)>{});
             m_prefetch(S_U, S_UP1);
 #if !(FA_PP16_ABL & 3)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             // pieces of the PREVIOUS phase and leaves K(u+2) in flight across the barrier - but the other group's half of K(u+2) is then retired
             // one barrier after this group starts reading the tile
 #if FA_PP16_DMA_DEBUG == 1
-            softmax_step(uu, no{}, no{}, mlc);
+            softmax_step(uu, no{}, no{}, mlc, no{});
             m_prefetch(S_U, S_UP1);
             dma_v_tile(v_srd, uu + 1, S_UP1);
             dma_k_tile(k_srd, uu + 1, S_UP1);      // (late issue: the K request this phase's counted wait retires)
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #else
             dma_v_tile(v_srd, uu + 1, S_UP1);
             dma_k_tile(k_srd, uu + 2, S_UM1);
-            softmax_step(uu, no{}, no{}, mlc);
+            softmax_step(uu, no{}, no{}, mlc, no{});
             m_prefetch(S_U, S_UP1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
             __syncthreads();
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #else
             if (uu + 2 < n_tiles) dma_k_tile(k_srd, uu + 2, S_UM1);
             if (uu + 1 < n_tiles) dma_v_tile(v_srd, uu + 1, S_UP1);
-            softmax_step(uu, no{}, no{}, mlc);
+            softmax_step(uu, no{}, no{}, mlc, no{});
             m_prefetch(S_U, S_UP1);
             end_s_phase();
 #endif
@@ -749,7 +762,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             __syncthreads();
             issue_dma_k(u);
             issue_dma_v(u);
-            softmax_step(u, no{}, no{}, no{});
+            softmax_step(u, no{}, no{}, no{}, no{});
             prev_ml = false;
             m_prefetch(ring_u, ring_up1);
             end_s_phase();
