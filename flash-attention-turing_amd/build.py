@@ -145,7 +145,18 @@ def build_kernels(force=False):
             raise RuntimeError("hipcc failed (M0 guard pass)")
         with open(asm) as f:
             n = m0_uses_outside_asm(f.read())
+        # MFMA-result guard (round 5): the accumulating MFMAs of the 16x16x32 kernels are inline asm, hipcc's hazard recogniser does not see them, and the forward's
+        # steady loop relies on the instructions between a tile's last MFMA and the first score read instead of a pad (fa_fwd_pp16.hip: `covered`).  mfma_hazards.py
+        # walks the ISA; a finding means this compiler scheduled a reader too close behind its MFMA.
+        sys.path.insert(0, HERE)
+        import mfma_hazards
+
+        found = {k: v for k, v in mfma_hazards.scan_file(asm).items() if v}
         os.remove(asm)
+        if found:
+            k, v = next(iter(found.items()))
+            raise RuntimeError(f"{os.path.basename(s)}: {sum(len(x) for x in found.values())} instruction(s) touch an MFMA result before it has landed, e.g. in {k}: "
+                               f"line {v[0][0]} `{v[0][1]}` {v[0][4]} of {v[0][5]} wait states behind `{v[0][3]}` (flash-attention-turing_amd/mfma_hazards.py)")
         if n:
             raise RuntimeError(f"{os.path.basename(s)}: {n} use(s) of M0 outside the hand-written asm statements - the unsaved-M0 LDS-DMA of these kernels is "
                                "no longer safe with this compiler / this edit (fa_params.hpp FA_BWD_DMA_SAVE_M0, fa_device.hpp dma16_to_lds_hidden)")

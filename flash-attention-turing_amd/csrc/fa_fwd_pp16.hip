@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     };
     // `mlc`: this tile's row sums go through the matrix pipe (no VALU adds, packed-max guard) / stay exact in the VALU
     // `covered`: the caller has put >= 8 wait states of its own between the tile's last MFMA and this call (the steady loop: barrier + the fused DMA statement,
-    // 18 of them) - the pad is then dropped, the register ties below stay (round 5; tests/_mfma_hazards.py counts the states in every instance's ISA)
+    // 18 of them) - the pad is then dropped, the register ties below stay (round 5; flash-attention-turing_amd/mfma_hazards.py counts the states in every instance's ISA)
     auto softmax_step = [&](int u, auto masked, auto maybe_first, auto mlc, auto covered) __attribute__((always_inline)) {
         constexpr bool MLT = ML && decltype(mlc)::value;
         // the scores were written by MFMAs issued from inline asm, which the hazard recogniser does not see: a 4-pass XDL write needs its
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         if constexpr (!decltype(covered)::value) asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
         // ... and the pad has to NAME the registers it protects: its "memory" clobber orders memory operations only, and hipcc is free to schedule a
         // register-only v_fma / v_exp that reads a score directly behind the MFMA that produces it, above the barrier and this pad (round 5, the 384-row
-        // experiment build: v_fma_f32 two instructions behind its MFMA, P wrong by ~0.1; tests/_mfma_hazards.py walks the ISA of every instance for it).
+        // experiment build: v_fma_f32 two instructions behind its MFMA, P wrong by ~0.1; flash-attention-turing_amd/mfma_hazards.py walks the ISA of every instance for it).
         // Volatile asm statements keep their order, so nothing that reads sacc can move above these (no instructions are emitted).
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
