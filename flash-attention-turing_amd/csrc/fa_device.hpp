@@ -250,6 +250,17 @@ FA_DEV void dma16x4_to_lds_hidden(const srd_t& srd, uint32_t tile_off, uint32_t 
                  : "memory", "scc");
 }
 
+// ... and TWO consecutive pieces (fa_fwd_pp.hip: a wave moves two pieces of K and two of V per tile)
+FA_DEV void dma16x2_to_lds_hidden(const srd_t& srd, uint32_t tile_off, uint32_t g0, uint32_t g1, uint32_t lds_byte_addr) {
+    uint32_t t;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 m0, %1\n\tv_add_u32 %0, %2, %3\n\tbuffer_load_dwordx4 %0, %5, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\tv_add_u32 %0, %2, %4\n\tbuffer_load_dwordx4 %0, %5, 0 offen lds"
+                 : "=&v"(t)
+                 : "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr)), "s"(__builtin_amdgcn_readfirstlane(tile_off)), "v"(g0), "v"(g1), "s"(srd)
+                 : "memory", "scc");
+}
+
 FA_DEV u32x4 lds_read16(const FA_LDS char* base, uint32_t off) { return *(const FA_LDS u32x4*)(base + off); }
 FA_DEV void lds_write16(FA_LDS char* base, uint32_t off, u32x4 v) { *(FA_LDS u32x4*)(base + off) = v; }
 FA_DEV void lds_write8(FA_LDS char* base, uint32_t off, u32x2 v) { *(FA_LDS u32x2*)(base + off) = v; }

@@ -59,6 +59,9 @@ constexpr float kPpDeferLog2 = 6.0f;
 //              each, the phase hand-over) weigh half as much; 5-9 % faster under a causal mask from 2k keys on in round 3, only from
 //              16k keys on since the causal dispatch order of round 4 (fa_params.hpp:causal_group_heads) took the imbalance away.
 // Measured ladder 256 .. 16k, both shapes, causal or not: profiles/r3_fwd_d64_tile_ab.log.  -DFA_FWD_D64_BN=64 / 128 pins one shape (A/B).
+#ifndef FA_PP_DMA_FUSED
+#define FA_PP_DMA_FUSED 1      // (round 5) a wave's two pieces of a K (or V) tile as one asm statement (fa_device.hpp:dma16x2_to_lds_hidden), as in fa_fwd_pp16.hip
+#endif
 #ifndef FA_FWD_D64_BN
 #define FA_FWD_D64_BN 0
 #endif
@@ -209,10 +212,16 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
     auto dma_k_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
+#if FA_PP_DMA_FUSED
+        if constexpr (DPW == 2) { dma16x2_to_lds_hidden(srd, (uint32_t)(t * kFwdBlockN) * k_rowb, dma_goff_k[0], dma_goff_k[1], lds_k0 + slot * TILEB); return; }
+#endif
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * k_rowb + dma_goff_k[i], lds_k0 + slot * TILEB + i * 1024);
     };
     auto dma_v_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
+#if FA_PP_DMA_FUSED
+        if constexpr (DPW == 2) { dma16x2_to_lds_hidden(srd, (uint32_t)(t * kFwdBlockN) * v_rowb, dma_goff_v[0], dma_goff_v[1], lds_v0 + slot * TILEB); return; }
+#endif
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
     };

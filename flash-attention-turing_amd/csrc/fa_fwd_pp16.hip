@@ -260,11 +260,17 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     int ring_u = 0, ring_um1 = 2, ring_up1 = 1;       // slot of tile u, of u-1 (== u+2), of u+1 in the 3-deep rings
     auto dma_k_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * k_rowb + dma_goff_k[i], lds_k0 + slot * TILEB + i * 1024);
+        for (int i = 0; i < (FA_PP16_DMA_FUSED && DPW == 2 ? 0 : DPW); ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * k_rowb + dma_goff_k[i], lds_k0 + slot * TILEB + i * 1024);
+#if FA_PP16_DMA_FUSED
+        if constexpr (DPW == 2) dma16x2_to_lds_hidden(srd, (uint32_t)(t * kFwdBlockN) * k_rowb, dma_goff_k[0], dma_goff_k[1], lds_k0 + slot * TILEB);
+#endif
     };
     auto dma_v_tile = [&](const srd_t& srd, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < DPW; ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
+        for (int i = 0; i < (FA_PP16_DMA_FUSED && DPW == 2 ? 0 : DPW); ++i) dma16_to_lds_hidden<false>(srd, (uint32_t)(t * kFwdBlockN) * v_rowb + dma_goff_v[i], lds_v0 + slot * TILEB + i * 1024);
+#if FA_PP16_DMA_FUSED
+        if constexpr (DPW == 2) dma16x2_to_lds_hidden(srd, (uint32_t)(t * kFwdBlockN) * v_rowb, dma_goff_v[0], dma_goff_v[1], lds_v0 + slot * TILEB);
+#endif
     };
 
 #if FA_PP16_ROLE_DMA
