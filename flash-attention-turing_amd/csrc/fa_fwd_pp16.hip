@@ -277,9 +277,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     const srd_t r_srd = group ? v_srd : k_srd;
     auto dma_role_tile = [&](int t, int slot) __attribute__((always_inline)) {      // group A: K(t), group B: V(t)
 #pragma unroll
-        for (int i = 0; i < (FA_PP16_DMA_FUSED && RPW == 4 ? 0 : RPW); ++i) dma16_to_lds_hidden<false>(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb + dma_goff_r[i], lds_r0 + slot * TILEB + i * 1024);
+        for (int i = 0; i < (FA_PP16_DMA_FUSED && (RPW == 4 || RPW == 2) ? 0 : RPW); ++i) dma16_to_lds_hidden<false>(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb + dma_goff_r[i], lds_r0 + slot * TILEB + i * 1024);
 #if FA_PP16_DMA_FUSED
         if constexpr (RPW == 4) dma16x4_to_lds_hidden(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb, dma_goff_r[0], dma_goff_r[1], dma_goff_r[2], dma_goff_r[3], lds_r0 + slot * TILEB);
+        if constexpr (RPW == 2) dma16x2_to_lds_hidden(r_srd, (uint32_t)(t * kFwdBlockN) * r_rowb, dma_goff_r[0], dma_goff_r[1], lds_r0 + slot * TILEB);      // (32-key tiles of the experiment build)
 #endif
     };
 #endif
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #if !(FA_PP16_ABL & 2)
             dma_role_tile(uu + 2, S_UM1);
 #endif
-            softmax_step(uu, no{}, no{}, mlc, std::integral_constant<bool, FA_PP16_DMA_FUSED && !(FA_PP16_ABL & 2) && FA_PP16_SKIP_PAD && (BN * (D / 8) / 256 == 4)>{});
+            softmax_step(uu, no{}, no{}, mlc, std::integral_constant<bool, FA_PP16_DMA_FUSED && !(FA_PP16_ABL & 2) && FA_PP16_SKIP_PAD && (BN * (D / 8) / 256 == 4 || BN * (D / 8) / 256 == 2)>{});      // (12 wait states with the two-piece statement)
             m_prefetch(S_U, S_UP1);
 #if !(FA_PP16_ABL & 3)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
