@@ -569,12 +569,15 @@ int set_kernel_policy(int policy) {
     if (policy < 0 || policy > 2) return -1;
     return g_fwd_policy.exchange(policy, std::memory_order_relaxed);
 }
-constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 22;             // 2048 x 2048
+// Round 5: with the softmax-phase trim (fa_fwd_pp16.hip: fused LDS-DMA statement, no pad) the 16x16x32 kernel is ahead from 1k x 1k without a mask (ratio 16 / 32 on
+// the b4 h32 grid: 1.00 at 512, 0.965 at 1k, 0.95 at 1.5k, 0.94 at 2k, 0.89 at 8k; bf16 0.97 at 1k) and from ~3k x 3k under one (0.985 at 1k-1.5k, 0.99 at 2k, 0.975 at 3k,
+// 0.96 at 4k): thresholds 2^22 -> 2^20 and 2^24 -> 2^23 (profiles/r5_policy_sweep_after_trim.log).
+constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 20;             // 1024 x 1024 (rounds 3-4: 2048 x 2048)
 // Under a causal mask the late waves of a workgroup idle while the early ones finish, the cap binds less and the break-even sits higher.
 // Round 4: with the row sums in the matrix pipe (fp16) the 16x16x32 kernel is ahead from 4k x 4k on (ratio 16 / 32: 0.96 at 4k, 0.94 at 8k,
 // 0.92 at 16k; round 3 without it, three other boxes: 0.98..1.03 / 1.00..1.02 / 1.00), so the threshold came down from 8k x 8k
 // (profiles/r4_policy_sweep_after_rowsum.log next to profiles/r3_policy_sweep.log; bf16 keeps its VALU row sums and sits within +-2.5 % there).
-constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 24;       // 4096 x 4096
+constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 23;       // ~2896 x 2896 (round 4: 4096 x 4096)
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
 int fwd_pp16_block_m(int d);                                                                          // query rows per workgroup of that kernel
 

@@ -665,6 +665,8 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
             // group A: K(u+2) -> the slot K(u-1) left (last read in M(u-1), which group B finished one barrier ago);
             // group B: V(u+2) -> the slot V(u-1) left (last read in M(u), which group B itself has just finished and group A one phase earlier).
             // Retired: the tile requested one softmax phase ago (K(u+1) / V(u+1)), by count - this phase's four pieces stay in flight.
+            // The requests stand BEHIND the barrier on purpose: a wave moves pieces of the whole tile, and the other waves of its own group may still be inside
+            // M(u) reading V(u-1) when the first one gets here - issued in front of the barrier they raced on one shape (round 5, profiles/r5_fwd_sphase_trim_ab.log (d)).
 #if FA_PP16_DMA_DEBUG == 1
             // LATE ISSUE: the request the counted wait of this phase would retire (tile u+1, made one phase ago in the product) goes out here instead
             softmax_step(uu, no{}, no{}, mlc, no{});

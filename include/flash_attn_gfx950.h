@@ -202,7 +202,7 @@ double fa_fwd_flops(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, in
 double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d);
 /* Name of the forward kernel the library dispatches LARGE problems of this head_dim to (what a profiler's kernel trace of the
  * BASELINE configurations will show; lets a benchmark tie a committed PMC profile to the kernel that actually ran).  head_dim 128
- * has two kernels: problems of seqlen_q * seqlen_k < 2^22 (2^24 under a causal mask) run fa_fwd_pp_kernel, larger ones
+ * has two kernels: problems of seqlen_q * seqlen_k < 2^20 (2^23 under a causal mask; until round 5: 2^22 / 2^24) run fa_fwd_pp_kernel, larger ones
  * fa_fwd_pp16_kernel; head_dim 64 likewise for fp16 inputs from 2^24 (2^26 under a causal mask) - the answer given here - while bf16
  * inputs stay on fa_fwd_pp_kernel at every size (fa_kernel_name_dtype answers per dtype). */
 const char* fa_fwd_kernel_name(int32_t d);

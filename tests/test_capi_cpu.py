@@ -44,6 +44,8 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.kernel_name("dq", 4, 16384, 16384, 32, 128, True) == "fa_bwd_dq16_kernel"       # round 4: causal dQ from 2^28 pairs per head
     assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 128, True) == "fa_fwd_pp16_kernel"          # round 4: causal forward from 2^24 (was 2^26)
     assert capi.kernel_name("fwd", 4, 2048, 2048, 32, 128, True) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 4, 3072, 3072, 32, 128, True) == "fa_fwd_pp16_kernel"          # round 5: causal forward from 2^23, ...
+    assert capi.kernel_name("fwd", 4, 1024, 1024, 32, 128, False) == "fa_fwd_pp16_kernel"         # ... non-causal from 2^20 (was 2^22)
     assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 128, False) == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dkdv", 4, 512, 512, 32, 128, True) == "fa_bwd_dkdv_kernel"
