@@ -3,7 +3,7 @@
 #   1. plain `python bench.py` (the driver's command)                                   -> bench_stdout.json
 #   2. rocprofv3 --kernel-trace --stats of the SAME command, headline (c3) and c4       -> bench_stats/, bench_c4_stats/
 #   3. HBM counters, FETCH_SIZE and WRITE_SIZE in separate --pmc passes (kernel-trace only), forward at C3 and backward at C4
-#   4. shader counters (three groups, separate passes), same two cases
+#   4. shader counters (four groups, separate passes), same two cases
 # tools/round_evidence_collect.py then writes profiles/rNN_* with the library's source digest and the git commit in every summary.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -18,7 +18,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/fwd_c3_$ctr" -- python "$R/tools/run_fwd_once.py" --seq 16384 --causal 1 --iters 4 > "$OUT/fwd_c3_$ctr.stdout" 2>&1; echo "fwd c3 $ctr rc=$?"
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/bwd_c4_$ctr" -- python "$R/tools/run_bwd_once.py" 4 8192 32 32 128 bf16 0 4 > "$OUT/bwd_c4_$ctr.stdout" 2>&1; echo "bwd c4 $ctr rc=$?"
 done
-GROUPS_=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS")
+GROUPS_=("SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU")
 i=0
 for grp in "${GROUPS_[@]}"; do
   i=$((i+1))

@@ -61,6 +61,11 @@ def derive(k):
         d["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
     if c.get("SQ_INSTS_LDS"):
         d["valu_insts_per_lds_inst"] = c.get("SQ_INSTS_VALU", 0.0) / c["SQ_INSTS_LDS"]
+    if c.get("SQ_INSTS_VMEM_RD") and c.get("SQ_INSTS_LDS"):
+        # wave-level vector-memory loads (LDS-DMA pieces, statistics, Q / dO / O rows) against LDS instructions: a per-tile figure follows from the kernel's known
+        # LDS instructions per wave and tile (the vector-memory issue cost of dK/dV)
+        d["vmem_rd_insts_per_lds_inst"] = c["SQ_INSTS_VMEM_RD"] / c["SQ_INSTS_LDS"]
+        d["vmem_wr_insts_per_lds_inst"] = c.get("SQ_INSTS_VMEM_WR", 0.0) / c["SQ_INSTS_LDS"]
     return d
 
 
