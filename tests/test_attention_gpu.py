@@ -128,7 +128,7 @@ def test_reference_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, d, caus
             dq_n, dk_n, dv_n = A.attn_bwd(n(q), n(k), n(v), o_n, lse_n, n(do), causal=causal, round_mode=A.ROUND_FP16)
             o_ref, lse_ref, dq_ref, dk_ref, dv_ref = (torch.from_numpy(x) for x in (o_n, lse_n, dq_n, dk_n, dv_n))
             # mean_rel is measured against exact math for kernel and oracle alike (tests/_util.py:check_mean_rel, rule "oracle")
-            xo, _, xdq, xdk, xdv = U.torch_attention_ref(q, k, v, do, causal, device="cpu", dtype=torch.float64)
+            xo, _, xdq, xdk, xdv = U.torch_attention_ref(q, k, v, do, causal, dtype=torch.float64)      # (fp64 on the GPU: the same exact expectation, without the CPU autograd round trip)
             orc = dict(O=(o_n, xo), dQ=(dq_n, xdq), dK=(dk_n, xdk), dV=(dv_n, xdv))
         else:
             o_ref, lse_ref, dq_ref, dk_ref, dv_ref = U.torch_attention_ref(q, k, v, do, causal)
@@ -244,7 +244,7 @@ def test_reference_varlen_grid_vs_torch_fp32(gpu, batch_size, nheads, nheads_k, 
                 dq_n, dk_n, dv_n = A.attn_bwd(n(qi), n(ki), n(vi), o_n, lse_n, n(doi), causal=causal, round_mode=A.ROUND_FP16)
                 refs = dict(O=o_n[0], dQ=dq_n[0], dK=dk_n[0], dV=dv_n[0])
                 lse_r = torch.from_numpy(lse_n)[0]
-                xo, _, xdq, xdk, xdv = U.torch_attention_ref(qi, ki, vi, doi, causal, device="cpu", dtype=torch.float64)
+                xo, _, xdq, xdk, xdv = U.torch_attention_ref(qi, ki, vi, doi, causal, dtype=torch.float64)
                 extra = {t: dict(oracle=refs[t], exact=x[0].cpu().numpy()) for t, x in (("O", xo), ("dQ", xdq), ("dK", xdk), ("dV", xdv))}
             else:
                 o_r, lse_r, dq_r, dk_r, dv_r = U.torch_attention_ref(qi, ki, vi, doi, causal)
