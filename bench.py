@@ -192,13 +192,19 @@ def strong_scaling_sweep(dist, make_point, sync_fn, device, seqs=SWEEP_SEQS, cau
     make_point(seq, causal, plan) -> (step_shard, step_whole): callables running this rank's shard / the whole problem once.
     Per point: rank 0 alone times the whole problem (the in-run N = 1 reference), then all ranks time their shards between
     barriers; aggregate TFLOP/s = whole-problem FLOPs / MAX-over-ranks time; efficiency = aggregate / (N x single-GPU rate)."""
-    from flash_attn_turing.sharding import plan_shards
+    from flash_attn_turing.sharding import plan_shards, problem_policy
 
     plan = plan_shards(b, h, hk, dist.world)[dist.rank]
     out = {}
     for causal in causals:
         for seq in seqs:
-            step_shard, step_whole = make_point(seq, causal, plan)
+            step_shard_own, step_whole = make_point(seq, causal, plan)
+
+            def step_shard(f=step_shard_own):
+                # the shard is served by the kernels the WHOLE problem gets (FA_POLICY_AUTO sizes a launch by its workgroups; a shard states the whole problem's
+                # batch x heads): its results are bit-identical to the unsharded call's, tests/test_properties_gpu.py
+                with problem_policy(b, h):
+                    f()
             iters = 20 if seq <= 4096 else 6
             flops = fwd_flops(b, seq, seq, h, d, causal)
             single = None
@@ -214,7 +220,7 @@ def strong_scaling_sweep(dist, make_point, sync_fn, device, seqs=SWEEP_SEQS, cau
                     "seq": seq, "causal": causal, "ms": wall / iters * 1e3, "aggregate_tflops": agg,
                     "frac_of_fp16_mfma_peak": agg / (PEAK_DENSE_FP16_TFLOPS * dist.world),
                     "single_gpu_tflops_same_run": single, "efficiency_vs_1gpu": agg / (single * dist.world),
-                    "units_total": units,
+                    "units_total": units, "shard_kernel_policy": "whole problem's (flash_attn_turing.sharding.problem_policy)",
                     "shard": f"batch [{plan.batch_start},{plan.batch_stop}) x kv heads [{plan.head_k_start},{plan.head_k_stop}) on rank 0"}
     return out
 

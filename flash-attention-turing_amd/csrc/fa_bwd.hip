@@ -789,7 +789,6 @@ hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t s) {
 constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 20;       // seqlen_q * seqlen_k per head: 1024 x 1024, causal or not, since its ring addressing
                                                               // costs one XOR per base register and tile (profiles/r3_policy_sweep.log, second table:
                                                               // -2..-8 % from 1k on, +-1.5 % at 512); per head, not per launch: fa_fwd_pp.hip says why
-constexpr int64_t kDqMfma16MinPairsCausal = (int64_t)1 << 28;
 // head_dim 64 (round 5): both backward kernels also exist in the 16x16x32 tiling (fa_bwd_dq16.hip with 128-key tiles, fa_bwd_dkdv16.hip), one workgroup
 // per compute unit on 160-180 registers against two co-resident workgroups of the 32x32x16 kernels on 128.  Measured, interleaved, two boxes
 // (profiles/r5_bwd_d64_mfma16_ab.log, time 16 / 32 at b4 h32): dQ without a mask 0.92 / 0.96 / 0.92 / 0.91 / 0.89 / 0.89 at 512 .. 16k, under a causal mask
@@ -818,9 +817,14 @@ static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
         // (seqlen_k < seqlen_q under a mask: blocks of dead rows, where the narrow kernels are ahead)
         return min_pairs > 0 && (int64_t)kp.seqlen_q * kp.seqlen_k >= min_pairs && !(kp.is_causal && kp.seqlen_k < kp.seqlen_q);
     }
-    // dQ: without a mask always; under a causal mask from 16k x 16k, where every box measured so far has it ahead (ratio 16 / 32 at 16k:
-    // 0.99, 0.97, 0.94, 0.97; at 8k 0.98 .. 1.03: profiles/r3_policy_sweep.log, r4_policy_sweep_after_rowsum.log)
-    if (!dkdv) return !kp.is_causal || (int64_t)kp.seqlen_q * kp.seqlen_k >= kDqMfma16MinPairsCausal;
+    // dQ (round 6): like the forward, by whether the launch fills the chip - from one 256-row workgroup per compute unit without a mask, from two under one (and then
+    // from 1k x 1k).  Ratio 16 / 32 (profiles/r6_policy_small_grids.log, r5_policy_sweep_after_trim.log): no mask b1 h8 1.05 at 512-4k (16-128 workgroups), 0.92 at 8k
+    // (256); b1 h32 1.03-1.04 at 512-1k (64-128), 0.935 at 2k (256); b4 h32 0.96 at 512 (256).  Causal: b1 h8 1.06-1.08 up to 4k (128), 1.03 at 8k (256); b1 h32 1.02 at
+    // 2k (256), 0.96 at 4k (512), 0.95 at 8k; b4 h32 1.01 at 512 (256), 0.98 at 1k (512), 0.97-0.98 up to 8k.  (Rounds 3-5: always without a mask, from 2^28 pairs under one.)
+    if (!dkdv) {
+        const int64_t wgs = policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_q + 255) / 256), cus = device_cu_count();
+        return kp.is_causal ? (wgs >= 2 * cus && (int64_t)kp.seqlen_q * kp.seqlen_k >= kKvMfma16MinPairs) : wgs >= cus;
+    }
     return (int64_t)kp.seqlen_q * kp.seqlen_k >= kKvMfma16MinPairs;
 }
 const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv) {
@@ -847,7 +851,7 @@ int64_t dkdv_workspace_bytes(const BwdKernelParams& kp, int32_t n_split) {
 // CUs of the CURRENT device (the split target is "workgroups per CU"), cached per device id (a process may drive devices or partitions with
 // different CU counts: ADVICE r3); 256 = MI355X when there is no usable device (host-only callers such as fa_bwd_workspace_bytes on a build box).
 // Consequence, stated in the public header: the summation order of GQA / MQA dK / dV with a workspace depends on the device's CU count.
-static int64_t device_cu_count() {
+int64_t device_cu_count() {
     static std::atomic<int> cache[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) {

@@ -31,6 +31,12 @@ namespace fa {
 #ifndef FA_KV16_DMA_EARLY
 #define FA_KV16_DMA_EARLY 0   // which q-half group requests the next tile at the top of the loop (the other one after its S / dP MFMAs); 2 = both at the top
 #endif
+// FA_KV16_DMA_STAGGER (round 6 experiment): four request points per tile instead of two - waves 0, 1 at the top of the tile, waves 2, 3 behind the second k-step of their
+// S / dP MFMAs, waves 4, 5 behind their S / dP MFMAs, waves 6, 7 behind their exponentials - so that at most two waves (on different SIMDs, never SIMD partners) queue at the
+// CU's address path at a time.  (Not the per-wave spread of round 5: a wave still issues its four pieces back to back.)
+#ifndef FA_KV16_DMA_STAGGER
+#define FA_KV16_DMA_STAGGER 0
+#endif
 // (Round 5, measured and not kept - code in the history at 1ef1631: FA_KV16_DMA_SPREAD, the four pieces issued one by one between the MFMAs of the S / dP k-steps
 // (+1.5..6 %) or of the dV / dK fragment steps (+5..23 %) instead of back to back, profiles/r5_bwd_dkdv_dma_spread_ab.log.)
 #ifndef FA_KV16_STAT_PRED
@@ -74,8 +80,18 @@ struct LP16<__bf16> {
 #define FA_KV16_D64_VREG 2    // head_dim 64: both k-steps of V live in registers next to both of K (16 + 16 registers)
 #endif
 
+// -DFA_KV_TIMING (development aid, tools/phase_timing_dkdv.py --layout 16): per-wave s_memtime stamps at the phase edges of the tile loop, summed per phase, plus the
+// workgroup's prologue / epilogue cycles and its start / end on the 100 MHz wall clock, left in p.ws[(block * 8 + wave) * 16 + ...] (the caller passes a workspace)
+#ifdef FA_KV_TIMING
+#define FA_KV16_STAMP(i) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define FA_KV16_STAMP(i) do { } while (0)
+#endif
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv16_kernel(const BwdKernelParams p) {
+#ifdef FA_KV_TIMING
+    const uint64_t t_start = __builtin_amdgcn_s_memtime(), rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
     static_assert(D == 128 || D == 64, "head_dim");
     constexpr int KS = D / 32, DB = D / 16, ROWB = D * 2, SLOTS = D / 8;
     constexpr int KVB = kKvBlockN * ROWB;                   // the workgroup's K (or V) tile
@@ -262,6 +278,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
     if (qh == 0) __builtin_amdgcn_s_setprio(1);
 #endif
     int cur_tile = 0;
+#ifdef FA_KV_TIMING
+    uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const uint64_t t_loop = tlast;
+#endif
     for (int it = 0; it < n_iters; ++it) {
 #if FA_KV_PRIO == 2
         if ((it ^ qh) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
@@ -275,7 +295,11 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
         FA_LDS char* sbuf = stat + buf * STATB;
 #endif
         const bool more = (it + 1 < n_iters);
-#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
+#if FA_KV16_DMA_STAGGER
+        // request point of this wave: 0 top, 1 mid S / dP, 2 behind S / dP, 3 behind the exponentials  (2 = three points: waves 0, 1 top; 2, 3 behind the exponentials; 4-7 behind S / dP)
+        const int dma_pt = FA_KV16_DMA_STAGGER == 2 ? (wave < 2 ? 0 : wave < 4 ? 3 : 2) : wave >> 1;
+        if (more && dma_pt == 0) issue_tile(buf ^ 1);
+#elif !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
         if (more && (FA_KV16_DMA_EARLY == 2 || qh == FA_KV16_DMA_EARLY)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
 #endif
         // Only the two statistics waves need this load, and a vector-memory instruction costs its wave ~100 cycles whatever it returns.  A LANE-dependent condition
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
         // wave-uniform `wave < 2` (a scalar branch) cost the non-causal instances 8-12 % (profiles/r4_bwd_dkdv16_ablations.log 6, 7)
         float st_next = 0.f;
         if (!FA_KV16_STAT_PRED(CAUSAL) || tid < 128) st_next = load_stat(more);
+        FA_KV16_STAMP(0);                                   // top of the tile: LDS-DMA requests (waves 0-3), statistics load
 
         const int mh = m0 + 32 * qh;                       // first query row of this wave's half
         // (no wave-level causal skip, on purpose: fa_bwd.hip.  A fully masked wave-tile runs the body with P = dS = 0 by select.)
@@ -333,16 +358,23 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
                         sacc[i][kc] = LP<T>::mfma16(qa[i], kreg[ks][kc], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[i][kc]);      // S = Q K^T
                         dpacc[i][kc] = LP<T>::mfma16(da[i], vf[kc], ks == 0 ? nd4[i] : dpacc[i][kc]);                              // dP - D = dO V^T - D
                     }
+#if FA_KV16_DMA_STAGGER == 1
+                if (ks == KS / 2 - 1 && more && dma_pt == 1) issue_tile(buf ^ 1);
+#endif
             }
+            FA_KV16_STAMP(1);                               // S / dP MFMAs (with their row-fragment reads)
 #if FA_KV16_DMA_DEBUG == 2
             if (more && qh == 1) asm volatile("s_sleep 64" ::: "memory");
 #endif
-#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
+#if FA_KV16_DMA_STAGGER
+            if (more && dma_pt == 2) issue_tile(buf ^ 1);
+#elif !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
             if (more && FA_KV16_DMA_EARLY != 2 && qh == (FA_KV16_DMA_EARLY ^ 1)) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
 #endif
-#if FA_KV16_DMA_DEBUG != 1
+#if FA_KV16_DMA_DEBUG != 1 && !FA_KV16_DMA_STAGGER
             if (more) pf_advance();
 #endif
+            FA_KV16_STAMP(2);                               // LDS-DMA requests (waves 4-7), descriptors of the next tile
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #if FA_KV16_TOGGLE
@@ -368,6 +400,10 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sacc[i][kc][r] = (16 * i + r >= thr[kc]) ? sacc[i][kc][r] : 0.f;
             }
+#if FA_KV16_DMA_STAGGER
+            if (more && dma_pt == 3) issue_tile(buf ^ 1);
+            if (more) pf_advance();
+#endif
             // P and dS = P * (dP - D) (:1354), rounded (:1359-1360), as the B operands of the half's 32-query contraction
             u32x4 pfr[2], dsfr[2];
 #pragma unroll
@@ -397,6 +433,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
 #endif
                 return u32x4{a0.x, a0.y, a1.x, a1.y};
             };
+            FA_KV16_STAMP(3);                               // exponentials, mask, dS, conversions
             u32x4 frag[NST];
 #pragma unroll
             for (int j = 0; j < PF; ++j) frag[j] = rd_frag(j);
@@ -414,6 +451,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        FA_KV16_STAMP(4);                                   // dV / dK MFMAs (with their transposed reads)
 #if FA_KV16_DMA_DEBUG == 1
         if (more) { issue_tile(buf ^ 1); pf_advance(); }
 #endif
@@ -424,6 +462,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
 #if !(FA_KV16_ABL & 32)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (and statistics) have landed
 #endif
+        FA_KV16_STAMP(5);                                   // statistics store + vmcnt(0): the next tile's pieces have landed
 #if FA_KV16_TOGGLE
         // on to the other ring slot (inline asm: hipcc would otherwise re-derive the addresses from `buf` and put the adds back)
 #pragma unroll
@@ -435,7 +474,11 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
 #if !(FA_KV16_ABL & 1)
         __syncthreads();
 #endif
+        FA_KV16_STAMP(6);                                   // ring-slot toggle + workgroup barrier
     }
+#ifdef FA_KV_TIMING
+    const uint64_t t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: the loop's last barrier has passed, K / V tiles, rings and stats are dead, LDS is scratch (fa_bwd_dkdv_common.hpp
     // describes the steps; the accumulator layout differs: registers [db][kc][r] = d 16*db + 4*g + r of key key_loc + 16*kc) ----------
@@ -490,6 +533,22 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
     if (p.n_split == 1) {
         reduce_and_store(dkacc, p.scale, dk_rs, dk_rowb);
         reduce_and_store(dvacc, 1.0f, dv_rs, dv_rowb);
+#ifdef FA_KV_TIMING
+        if (p.ws != nullptr && lane == 0) {
+            const uint64_t t_end = __builtin_amdgcn_s_memtime(), rt_end = __builtin_amdgcn_s_memrealtime();
+            float* out = p.ws + ((int64_t)blockIdx.x * 8 + wave) * 16;
+            for (int i = 0; i < 7; ++i) out[i] = (float)tacc[i];
+            out[7] = (float)n_iters;
+            out[8] = (float)(t_loop - t_start);             // prologue
+            out[9] = (float)(t_end - t_loop_end);           // epilogue
+            out[10] = (float)(rt_start & 0xffffffull);       // wall clock, 100 MHz, low 24 bits
+            out[11] = (float)(rt_end & 0xffffffull);
+            out[12] = (float)tile; out[13] = (float)(batch * p.h_k + head_k);
+            uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            out[14] = (float)(xcc & 0xf); out[15] = (float)((hwid >> 8) & 0xff);      // XCD, (CU / SE bits of HW_ID)
+        }
+#endif
         return;
     }
     // split head group: the UNSCALED fp32 sum goes to this split's plane of the workspace (a key's row is 4 * D bytes there)

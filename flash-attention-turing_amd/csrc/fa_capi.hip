@@ -113,6 +113,7 @@ double fa_fwd_bytes(int32_t b, int32_t sq, int32_t sk, int32_t h, int32_t hk, in
 
 const char* fa_fwd_kernel_name(int32_t d) { return fa::fwd_kernel_name(d); }
 int32_t fa_set_kernel_policy(int32_t policy) { return fa::set_kernel_policy(policy); }
+int64_t fa_set_policy_problem_heads(int64_t batch_times_heads) { return fa::set_policy_problem_heads(batch_times_heads); }
 const char* fa_kernel_name(int32_t stage, int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t d, int32_t is_causal) {
     return fa_kernel_name_dtype(stage, FA_FP16, b, seqlen_q, seqlen_k, h, d, is_causal);
 }

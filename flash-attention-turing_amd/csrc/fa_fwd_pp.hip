@@ -569,15 +569,25 @@ int set_kernel_policy(int policy) {
     if (policy < 0 || policy > 2) return -1;
     return g_fwd_policy.exchange(policy, std::memory_order_relaxed);
 }
-// Round 5: with the softmax-phase trim (fa_fwd_pp16.hip: fused LDS-DMA statement, no pad) the 16x16x32 kernel is ahead from 1k x 1k without a mask (ratio 16 / 32 on
-// the b4 h32 grid: 1.00 at 512, 0.965 at 1k, 0.95 at 1.5k, 0.94 at 2k, 0.89 at 8k; bf16 0.97 at 1k) and from ~3k x 3k under one (0.985 at 1k-1.5k, 0.99 at 2k, 0.975 at 3k,
-// 0.96 at 4k): thresholds 2^22 -> 2^20 and 2^24 -> 2^23 (profiles/r5_policy_sweep_after_trim.log).
-constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 20;             // 1024 x 1024 (rounds 3-4: 2048 x 2048)
-// Under a causal mask the late waves of a workgroup idle while the early ones finish, the cap binds less and the break-even sits higher.
-// Round 4: with the row sums in the matrix pipe (fp16) the 16x16x32 kernel is ahead from 4k x 4k on (ratio 16 / 32: 0.96 at 4k, 0.94 at 8k,
-// 0.92 at 16k; round 3 without it, three other boxes: 0.98..1.03 / 1.00..1.02 / 1.00), so the threshold came down from 8k x 8k
-// (profiles/r4_policy_sweep_after_rowsum.log next to profiles/r3_policy_sweep.log; bf16 keeps its VALU row sums and sits within +-2.5 % there).
-constexpr int64_t kFwdMfma16MinPairsCausal = (int64_t)1 << 23;       // ~2896 x 2896 (round 4: 4096 x 4096)
+static std::atomic<int64_t> g_policy_bh{0};
+int64_t set_policy_problem_heads(int64_t bh) {
+    if (bh < 0) return -1;
+    return g_policy_bh.exchange(bh, std::memory_order_relaxed);
+}
+int64_t policy_bh(int64_t b, int64_t h) {
+    const int64_t hint = g_policy_bh.load(std::memory_order_relaxed);
+    return hint > 0 ? hint : b * h;
+}
+// Round 6: which head_dim-128 forward is ahead depends on whether the LAUNCH fills the chip, not only on the problem per head: below one workgroup per compute unit the
+// clock is not held down by the power cap and the 32x32x16 kernel (half the MFMA instructions) is 5-10 % ahead at every length; from one per unit (two under a causal
+// mask, whose workgroups carry half the work on average) the 16x16x32 kernel is 2-9 % ahead from 1k x 1k.  Ratio 16 / 32, fp16, profiles/r6_policy_small_grids.log next to
+// profiles/r5_policy_sweep_after_trim.log (workgroups of 256 query rows):
+//   no mask:  b1 h8   1k 1.08 (32 wg)  2k 1.07 (64)   4k 1.02 (128)  8k 0.91 (256) |  b1 h32  1k 1.05 (128)  2k 0.94 (256)  4k 0.92 |  b4 h32  512 1.00 (256)  1k 0.965 (512)  2k 0.94
+//   causal:   b1 h8   2k 1.10 (64)     4k 1.07 (128)  8k 0.97 (256)                |  b1 h32  2k 1.01 (256)  4k 0.95 (512)  8k 0.93 |  b4 h32  512 1.01 (256)  1k 0.985 (512)  4k 0.96
+// Rule: seqlen_q * seqlen_k >= 2^20 AND workgroups >= CUs (causal: >= 2 x CUs, or >= CUs with seqlen_q * seqlen_k >= 2^26).  Rounds 3-5 chose by the pairs per head alone
+// (2^20, 2^23 causal) so that a (batch, head) shard got the whole problem's kernel; a shard now states the whole problem's batch x heads (set_policy_problem_heads above).
+constexpr int64_t kFwdMfma16MinPairs = (int64_t)1 << 20;             // 1024 x 1024
+constexpr int64_t kFwdMfma16LongPairsCausal = (int64_t)1 << 26;      // 8192 x 8192: one workgroup per compute unit is enough under a mask
 hipError_t launch_fwd_pp16(const FwdKernelParams& kp, int dtype, uint32_t grid, hipStream_t stream);      // fa_fwd_pp16.hip
 int fwd_pp16_block_m(int d);                                                                          // query rows per workgroup of that kernel
 
@@ -592,9 +602,12 @@ static bool use_mfma16(const FwdKernelParams& kp, int dtype) {
     if (policy == 0 || (kp.d != 128 && kp.d != 64)) return false;
     if (policy == 1) return true;
     if (kp.d == 64) return dtype == 0 && (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kFwdD64Mfma16MinPairsCausal : kFwdD64Mfma16MinPairs);
-    // (packed sequences: max_seqlen_q x max_seqlen_k; never total_q - the optional hint must not change which kernel, hence which bits,
-    // a call gets: tests/test_fuzz_gpu.py compares the compact and the plain varlen grid bit for bit)
-    return (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kFwdMfma16MinPairsCausal : kFwdMfma16MinPairs);
+    // (packed sequences: max_seqlen_q x max_seqlen_k and the plain grid's workgroup count; never total_q - the optional hint must not change which kernel,
+    // hence which bits, a call gets: tests/test_fuzz_gpu.py compares the compact and the plain varlen grid bit for bit)
+    const int64_t pairs = (int64_t)kp.seqlen_q * kp.seqlen_k;
+    const int64_t wgs = policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_q + 255) / 256), cus = device_cu_count();
+    if (pairs < kFwdMfma16MinPairs) return false;
+    return kp.is_causal ? (wgs >= 2 * cus || (wgs >= cus && pairs >= kFwdMfma16LongPairsCausal)) : wgs >= cus;
 }
 
 // the kernel that serves the LARGE problems of a head dimension (what a profile of the BASELINE configurations shows)

@@ -95,6 +95,11 @@ constexpr float kPpDeferLog2 = 6.0f;
 #endif
 // (Round 5, measured and not kept: a bare s_barrier instead of __syncthreads() at the end of the steady loop's softmax phase, so that hipcc does not wait (lgkmcnt(0)) for the
 // fragments m_prefetch has just requested - bit-identical, no gain on top of the two switches above: the wave waits at that barrier anyway, profiles/r5_fwd_sphase_trim_ab.log.)
+// (Round 6, measured and not kept (the switches were never committed; the logs say what was built): FA_PP16_DMA_STAGGER, the four waves of a group requesting their role pieces a quarter of the
+// softmax pass apart instead of together behind the barrier: bit-identical, +9..41 % (the scalar branches inside the pass cost hipcc its schedule),
+// profiles/r6_fwd_dma_stagger_ab.log; FA_PP16_PK_FMA, the multiply-subtract in front of every exponential two scores at a time (v_pk_fma_f32, 95 -> 79 VALU per wave and
+// tile, bit-identical): +10..25 % - beside a partner wave that issues MFMAs a v_pk_fma_f32 takes 21 cycles where a v_fma_f32 takes 8 (tools/ubench, profiles/r6_ubench_cadence.log),
+// profiles/r6_fwd_pk_fma_ab.log.)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif

@@ -125,6 +125,11 @@ const char* fwd_kernel_name_for(const FwdKernelParams& kp, int dtype);          
 const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv);      // ... launch_bwd_dq / launch_bwd_dkdv
 int set_kernel_policy(int policy);      // FA_POLICY_* of the public header; returns the previous one, -1 for an unknown value
 int kernel_policy();
+// FA_POLICY_AUTO sizes a head_dim-128 launch by its workgroup count (round 6): (batch x heads) x tiles.  A caller that runs a (batch, head) SHARD of a problem and wants the
+// kernels - hence the bits - of the whole problem states the whole problem's batch x heads here (0 = the launch's own); flash_attn_turing/sharding.py:problem_policy
+int64_t set_policy_problem_heads(int64_t batch_times_heads);      // returns the previous value, -1 (and changes nothing) for a negative one
+int64_t policy_bh(int64_t b, int64_t h);                          // the batch x heads FA_POLICY_AUTO sizes this launch with
+int64_t device_cu_count();                                         // compute units of the current device (256 without one)
 hipError_t launch_bwd_dot_do_o(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dq(BwdKernelParams kp, int dtype, hipStream_t stream);
 hipError_t launch_bwd_dkdv(BwdKernelParams kp, int dtype, hipStream_t stream);

@@ -35,20 +35,20 @@ from .interface import (  # noqa: E402,F401
     FlashAttnFunc,
     FlashAttnVarlenFunc,
 )
-from .sharding import ShardPlan, plan_shards, shard_tensor  # noqa: E402,F401
+from .sharding import ShardPlan, plan_shards, shard_tensor, problem_policy  # noqa: E402,F401
 
 __all__ = [
     "fwd", "bwd", "varlen_fwd", "varlen_bwd",
     "flash_attn_func", "flash_attn_varlen_func", "FlashAttnFunc", "FlashAttnVarlenFunc",
-    "ShardPlan", "plan_shards", "shard_tensor", "LIBRARY_PATH", "EXTENSION_PATH",
+    "ShardPlan", "plan_shards", "shard_tensor", "problem_policy", "LIBRARY_PATH", "EXTENSION_PATH",
     "set_kernel_policy", "kernel_name",
 ]
 __version__ = "0.1.0"
 
 
 def set_kernel_policy(policy) -> str:
-    """Which of the two head_dim-128 kernel sets serves the launches of this process: "auto" (default: per launch by sequence length and
-    mask), "mfma32" or "mfma16" (C ABI fa_set_kernel_policy; both sets meet the same tolerances, they differ in speed only).  Returns the
+    """Which of the two head_dim-128 kernel sets serves the launches of this process: "auto" (default: per launch by sequence length, mask and
+    how far the launch fills the chip; `problem_policy` gives the shards of a problem the whole problem's choice), "mfma32" or "mfma16" (C ABI fa_set_kernel_policy; both sets meet the same tolerances, they differ in speed only).  Returns the
     previous policy's name.  No counterpart in the reference."""
     from . import capi
 

@@ -117,6 +117,8 @@ def lib():
         L.fa_kernel_name_dtype.restype = ctypes.c_char_p
         L.fa_set_kernel_policy.argtypes = [_i32]
         L.fa_set_kernel_policy.restype = _i32
+        L.fa_set_policy_problem_heads.argtypes = [ctypes.c_int64]
+        L.fa_set_policy_problem_heads.restype = ctypes.c_int64
         _lib = L
     return _lib
 
@@ -148,6 +150,14 @@ def set_kernel_policy(policy) -> int:
     prev = lib().fa_set_kernel_policy(int(policy))
     if prev < 0:
         raise ValueError(f"unknown kernel policy {policy}")
+    return prev
+
+
+def set_policy_problem_heads(batch_times_heads) -> int:
+    """fa_set_policy_problem_heads: the batch x heads FA_POLICY_AUTO sizes the following launches with (0 = each launch's own); returns the previous value"""
+    prev = lib().fa_set_policy_problem_heads(int(batch_times_heads))
+    if prev < 0:
+        raise ValueError(f"batch x heads must be >= 0, got {batch_times_heads}")
     return prev
 
 

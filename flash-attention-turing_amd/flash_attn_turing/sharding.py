@@ -5,6 +5,7 @@ work with NO collective: shard the batch first, and only when there are more ran
 entries split the kv-head groups as well (a GQA group is never split across ranks, so dK/dV
 need no cross-rank reduction).  Pure host logic: no torch device calls, unit-tested on CPU.
 """
+import contextlib
 from dataclasses import dataclass
 
 
@@ -69,3 +70,19 @@ def shard_tensor(t, plan: ShardPlan, is_kv: bool):
     if is_kv:
         return t[plan.batch_start:plan.batch_stop, :, plan.head_k_start:plan.head_k_stop]
     return t[plan.batch_start:plan.batch_stop, :, plan.head_start:plan.head_stop]
+
+
+@contextlib.contextmanager
+def problem_policy(batch: int, nheads: int):
+    """Run (batch, head) shards of a `batch` x `nheads` problem with the kernels the WHOLE problem would get, hence bit-identical to the unsharded call.
+    FA_POLICY_AUTO sizes a head_dim-128 launch by its workgroup count (include/flash_attn_gfx950.h, fa_set_kernel_policy); a shard is a smaller launch and
+    could otherwise be served by the other kernel set.  Process-wide state (C ABI fa_set_policy_problem_heads), restored on exit:
+        with problem_policy(b, h):
+            for plan in plan_shards(b, h, hk, world): ... fwd(shard_tensor(q, plan, False), ...)"""
+    from . import capi
+
+    prev = capi.set_policy_problem_heads(int(batch) * int(nheads))
+    try:
+        yield
+    finally:
+        capi.set_policy_problem_heads(prev)

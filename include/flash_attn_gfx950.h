@@ -202,17 +202,20 @@ double fa_fwd_flops(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, in
 double fa_fwd_bytes(int32_t b, int32_t seqlen_q, int32_t seqlen_k, int32_t h, int32_t h_k, int32_t d);
 /* Name of the forward kernel the library dispatches LARGE problems of this head_dim to (what a profiler's kernel trace of the
  * BASELINE configurations will show; lets a benchmark tie a committed PMC profile to the kernel that actually ran).  head_dim 128
- * has two kernels: problems of seqlen_q * seqlen_k < 2^20 (2^23 under a causal mask; until round 5: 2^22 / 2^24) run fa_fwd_pp_kernel, larger ones
- * fa_fwd_pp16_kernel; head_dim 64 likewise for fp16 inputs from 2^24 (2^26 under a causal mask) - the answer given here - while bf16
+ * has two kernels: fa_fwd_pp16_kernel serves problems of seqlen_q * seqlen_k >= 2^20 whose launch fills the chip (fa_set_kernel_policy below), fa_fwd_pp_kernel
+ * the others; head_dim 64 likewise for fp16 inputs from 2^24 (2^26 under a causal mask) - the answer given here - while bf16
  * inputs stay on fa_fwd_pp_kernel at every size (fa_kernel_name_dtype answers per dtype). */
 const char* fa_fwd_kernel_name(int32_t d);
 /* head_dim 128 has two sets of kernels, tiled for v_mfma_f32_32x32x16 and for v_mfma_f32_16x16x32.  Both meet the same tolerances;
  * they differ in speed only: the 16x16x32 shape draws less power per FLOP and wins where the chip's power cap binds (long launches),
- * the 32x32x16 forward needs fewer cycles and wins short ones.  FA_POLICY_AUTO (the default): forward and dK/dV by seqlen_q * seqlen_k (forward as
- * described above, dK/dV from 2^20), dQ 16x16x32 unless the mask is causal (then from 2^28) - per head, never by batch or head count, so a
- * (batch, head) shard of a problem gets the bits the whole problem gets (one exception: dK / dV of a GQA / MQA call that is given a
+ * the 32x32x16 forward needs fewer cycles and wins short ones and launches that leave compute units idle.  FA_POLICY_AUTO (the default, head_dim 128, round 6): the
+ * forward and dQ go to the 16x16x32 set when the launch has at least one 256-row workgroup per compute unit (batch x heads x ceil(seqlen_q / 256) >= CUs; under a causal
+ * mask two per unit, or one with seqlen_q * seqlen_k >= 2^26) and, forward and causal dQ, seqlen_q * seqlen_k >= 2^20; dK/dV from seqlen_q * seqlen_k >= 2^20 whatever the
+ * launch.  Because the choice follows the LAUNCH, a (batch, head) shard of a problem may get the other kernel set than the whole problem would: a caller that wants the
+ * whole problem's kernels, hence its bits, on every shard states the whole problem's batch x heads with fa_set_policy_problem_heads() before it runs the shards (rounds
+ * 3-5 chose per head only; flash_attn_turing/sharding.py:problem_policy does it for the Python surface).  One more exception stays: dK / dV of a GQA / MQA call that is given a
  * workspace - how far a head group is split, hence the order its partial sums are added in, follows the launch's workgroup count and the
- * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit); FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
+ * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit.  FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
  * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has both forward kernels since round 4 - FA_POLICY_AUTO sends fp16
  * problems from 2^24 pairs per head (2^26 causal) to the 16x16x32 one, whose softmax row sums ride the matrix pipe (-2..5 %), and keeps bf16 on the
  * 32x32x16 one - and both backward sets since round 5: FA_POLICY_AUTO gives dQ to the 16x16x32 kernel without a mask at every length and under a
@@ -226,6 +229,10 @@ const char* fa_fwd_kernel_name(int32_t d);
 #define FA_POLICY_MFMA16 1
 #define FA_POLICY_AUTO 2
 int32_t fa_set_kernel_policy(int32_t policy);
+/* The batch x heads FA_POLICY_AUTO sizes every following launch with, instead of the launch's own: the WHOLE problem's, stated by a caller that runs (batch, head) shards of
+ * it one after the other or on several devices and wants every shard served by the kernels the whole problem would get (bit-identical results).  0 (the initial value) = the
+ * launch's own batch x heads.  Process-wide, thread-safe; returns the previous value, -1 (and changes nothing) for a negative argument.  Round 6; the reference has no counterpart. */
+int64_t fa_set_policy_problem_heads(int64_t batch_times_heads);
 /* Name of the kernel a launch of this shape is dispatched to under the current policy (what a profiler's kernel trace will show):
  * stage FA_STAGE_FWD / FA_STAGE_DQ / FA_STAGE_DKDV; seqlen_* = the max_seqlen_* of a packed call.  "" for an unknown stage. */
 #define FA_STAGE_FWD 0

@@ -19,9 +19,12 @@ TOL = {
     "bf16": dict(max_abs=4e-2, mean_abs=1.6e-3, mean_rel=8e-2),
 }
 LSE_TOL = 1e-3
-ORACLE_OWN_CAP = 25      # check_mean_rel: the C oracle's own raw mean_rel may be at most this many times the plain tolerance
-ORACLE_BOUND_CAP = 10    # ... and a bound derived from it at most this many times the plain tolerance (was 2 x ORACLE_OWN_CAP = 50 everywhere),
-ORACLE_TINY_SK = 4       # except on problems of at most this many keys, where the reference algorithm itself reaches 0.18-0.23 (dQ at sk = 2) and 2 x its own stands
+ORACLE_OWN_CAP = 25      # check_mean_rel: the C oracle's own mean_rel may be at most this many times the plain tolerance (an oracle beyond it fails the test: drift)
+ORACLE_BOUND_CAP = 10    # ... and a bound derived from it at most this many times the plain tolerance,
+ORACLE_TINY_SK = 4       # except on problems of at most this many keys: there the reference algorithm itself reaches 0.18-0.23 (dQ at sk = 2), the derived bound may go as far
+                         # as the oracle's own cap (25 x; round 5: 50 x), and BOTH sides are measured against max(|e|, 1 % of the tensor's RMS) instead of max(|e|, 1e-6)
+ZERO_ABS_TOL = 2e-4      # rule "zero": |kernel value| where the expectation vanishes identically (fp32 summation-order noise of dP - D, ~1e-5 per dS element, summed over the
+                         # query rows and the GQA group of a key: up to ~1e-4 at 2048 rows x 6 heads; the output format does not enter)
 REL_EPS = 1e-6
 
 
@@ -67,7 +70,7 @@ def _record_margin(name, raw, dtype, plain):
     slot["plain_bound_cases"] += int(plain)
 
 
-REL_TABLE = []   # one row per mean_rel decision (family, case, tensor, dtype, kernel / oracle raw mean_rel, bound, rule) -> gpurun_out/mean_rel_table.json
+REL_TABLE = []   # one row per mean_rel decision (family, case, tensor, dtype, kernel / oracle raw mean_rel, bound, rule) -> gpurun_out/mean_rel_table_<stamp>.json (tests/conftest.py)
 
 
 def raw_mean_rel(x, e):
@@ -76,93 +79,68 @@ def raw_mean_rel(x, e):
     return float((np.abs(x - e) / np.maximum(np.abs(e), REL_EPS)).mean()) if x.size else 0.0
 
 
-def check_mean_rel(xa, e, dtype, name, scale, sk, oracle, e_unrounded=None, oracle_fn=None):
-    """mean_rel, the reference's third bound (test_flash_attn.py:117,412: plain mean(|d| / max(|ref|, 1e-6)) <= 1e-2), asserted RAW:
-      rule "oracle": the caller supplied the C oracle's result (the reference ALGORITHM in contract mode: P / dS / outputs rounded
-                     where the reference rounds them, everything else exact) for the same tensor.  Bound = max(1e-2, 2 x the
-                     oracle's own raw mean_rel against the same expectation): where the reference algorithm itself meets 1e-2 the
-                     kernel must meet the plain bound, where it provably cannot (a handful of keys: nothing averages the rounding of
-                     P / dS out; tools/mean_rel_oracle_table.py prints the oracle's side on the dev container) the kernel may be
-                     at most twice as far off as the algorithm is - but never more than ORACLE_BOUND_CAP (10) x the plain bound unless the
-                     problem has at most ORACLE_TINY_SK (4) keys (round 5; until then 50 x everywhere).
-      rule "plain":  no oracle result (large problems) and sk >= 64: the plain bound.
-      rule "zero":   the expectation is identically ~0 (max |e| < 1e-4): a single visible key makes dS = P (dP - D) vanish
-                     analytically, the oracle returns exact zeros, and ANY fp32 implementation that forms D = rowsum(dO * O) and
-                     dP = dO . V in different summation orders (the reference's own dot_do_o + tensor-core dP included) leaves
-                     ~1e-7 of noise whose relative error against 0 is unbounded: recorded, not asserted.  The same holds element-
-                     wise under rule "oracle": entries where expectation AND oracle are exactly 0 (dead rows, the single-key row 0
-                     of a causal square problem) are left out of both relative means (max_abs / mean_abs still cover them).
-      rule "floor":  neither (sk < 64 without an oracle result): elements below 1 % of the tensor's RMS are measured against 1 % of
-                     the RMS instead of against (nearly) zero.
-    Every decision is appended to REL_TABLE."""
+def check_mean_rel(xa, e, dtype, name, scale, sk, oracle, e_unrounded=None):
+    """mean_rel, the reference's third bound (test_flash_attn.py:117,412: plain mean(|d| / max(|ref|, 1e-6)) <= 1e-2).  FOUR rules, every one an assertion:
+      "oracle": the caller supplied the C oracle's result (the reference ALGORITHM in contract mode: P / dS / outputs rounded where the reference rounds
+                them, everything else exact) for the same tensor.  Bound = max(1e-2, 2 x the oracle's own mean_rel against the same expectation): where the
+                reference algorithm itself meets 1e-2 the kernel must meet the plain bound, where it provably cannot (a handful of keys: nothing averages
+                the rounding of P / dS out; tools/mean_rel_oracle_table.py prints the oracle's side on the dev container) the kernel may be at most twice as
+                far off as the algorithm is - never more than ORACLE_BOUND_CAP (10) x the plain bound, or ORACLE_OWN_CAP (25) x on problems of at most
+                ORACLE_TINY_SK (4) keys.  On those tiny problems kernel and oracle are both measured against max(|e|, 1 % of the tensor's RMS): one query
+                over two keys has dS_0 = -dS_1, so dQ = dS_0 (K_0 - K_1) is ~1e-6 wherever two fp16 key components nearly agree while the rounding of dS
+                leaves ~1e-4 there, and ONE such element puts the raw relative mean of the reference algorithm itself at 0.4 .. 1.7 (round 5, the packed
+                grid; that was a rule of its own then).  The oracle must pass its own sanity cap in the same metric.
+                Elements where expectation AND oracle are exactly 0 (dead rows, the single-key row 0 of a causal square problem) are left out of both
+                relative means (max_abs / mean_abs still cover them).
+      "plain":  no oracle result (large problems) and sk >= 64: the reference's plain bound.
+      "zero":   the expectation is identically ~0 (max |e| < 1e-4): a single visible key makes dS = P (dP - D) vanish analytically, the oracle returns exact
+                zeros, and ANY fp32 implementation that forms D = rowsum(dO * O) and dP = dO . V in different summation orders (the reference's own dot_do_o +
+                tensor-core dP included) leaves ~1e-7 .. 1e-5 of noise whose RELATIVE error against 0 is unbounded.  Asserted instead: max |kernel value| <=
+                ZERO_ABS_TOL (round 6; recorded without an assertion until then).
+      "floor":  neither (sk < 64 without an oracle result): elements below 1 % of the tensor's RMS are measured against 1 % of the RMS instead of against
+                (nearly) zero.
+    Every decision is appended to REL_TABLE with the asserted quantity (`asserted`) and its bound."""
     tol = TOL[dtype]["mean_rel"] * scale
     fam = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split("::")[-1].split(" ")[0]
-    row = dict(family=fam, case=name, dtype=dtype, kernel=raw_mean_rel(xa, e), oracle=None, bound=None, rule=None)
+    row = dict(family=fam, case=name, dtype=dtype, kernel=raw_mean_rel(xa, e), oracle=None, bound=None, rule=None, asserted=None)
     REL_TABLE.append(row)
     if float(np.abs(e).max(initial=0.0)) < 1e-4:
-        row.update(rule="zero")
+        zmax = float(np.abs(xa).max(initial=0.0))
+        row.update(rule="zero", bound=ZERO_ABS_TOL * scale, asserted=zmax)
+        assert zmax <= ZERO_ABS_TOL * scale, f"{name}: expectation vanishes identically, kernel max |x| = {zmax:.3e} > {ZERO_ABS_TOL * scale:.1e}"
         return
-    # Elements where BOTH the exact expectation and the oracle are exactly zero - dead rows; rows with a single visible key, where dS = 0
-    # analytically (causal row 0 of every square problem); cancellations such as dS_0 K_0 + dS_1 K_1 with two equal fp16 key components
-    # that survive the oracle's exact sums but not fp32 ones - carry no relative information: |x - 0| / 1e-6.  They are left out of
-    # the relative mean of kernel and oracle alike and stay under the max_abs / mean_abs bounds of assert_close.
-    nz = np.ones(e.shape, dtype=bool)
     if oracle is not None:
+        # Elements where BOTH the exact expectation and the oracle are exactly zero - dead rows; rows with a single visible key, where dS = 0
+        # analytically (causal row 0 of every square problem); cancellations such as dS_0 K_0 + dS_1 K_1 with two equal fp16 key components
+        # that survive the oracle's exact sums but not fp32 ones - carry no relative information: |x - 0| / 1e-6.  They are left out of
+        # the relative mean of kernel and oracle alike and stay under the max_abs / mean_abs bounds of assert_close.
+        oa = np.asarray(oracle, dtype=np.float64)
         eu = e if e_unrounded is None else np.asarray(e_unrounded, dtype=np.float64)
-        nz = ~((eu == 0.0) & (np.asarray(oracle, dtype=np.float64) == 0.0))
+        nz = ~((eu == 0.0) & (oa == 0.0))
         if not nz.all():
-            z = float(np.abs(xa[~nz]).max())
-            row.update(zero_elements=int((~nz).sum()), max_abs_on_zero_elements=z)       # (bounded by assert_close's max_abs check)
-    k_raw = raw_mean_rel(xa[nz], e[nz])
-    row["kernel_on_nonzero"] = k_raw
-    if oracle is not None:
-        o_raw = raw_mean_rel(np.asarray(oracle, dtype=np.float64)[nz], e[nz])
-        # the oracle may widen the bound only so far (ADVICE r3): the worst the reference algorithm itself has shown on the reference's grid
-        # is 0.23 (dQ, sq = sk = 2, fp16); an oracle that drifts past ORACLE_OWN_CAP x the plain tolerance fails here instead of silently
-        # loosening every bound derived from it, and no derived bound exceeds 2 x that
-        if o_raw > ORACLE_OWN_CAP * tol and sk is not None and sk <= ORACLE_TINY_SK:
-            # rule "oracle-floor" (round 5, the reference's varlen grid draws such sequences at random): ONE query row over TWO keys has dS_0 = -dS_1, so
-            # dQ = dS_0 (K_0 - K_1): wherever two fp16 key components nearly agree the exact value is ~1e-6 while the rounding of dS leaves ~1e-4, and a
-            # single such element puts the RAW relative mean of the reference algorithm itself above ORACLE_OWN_CAP x the bound (1.70 at lq = 1, lk = 2,
-            # 6 / 3 heads, d 64: tests/test_attention_gpu.py::test_reference_varlen_grid_vs_torch_fp32).  Such a tensor is measured with the "floor" rule's
-            # denominator max(|e|, 1 % of the tensor's RMS) for oracle and kernel alike; the oracle must then pass its own sanity cap, and the kernel
-            # gets the usual max(plain, 2 x oracle) under the usual cap.  Nothing that passed the raw form is re-routed here.
-            floor = max(REL_EPS, 0.01 * float(np.sqrt(np.mean(e * e))))
-            fl = lambda t: float((np.abs(np.asarray(t, dtype=np.float64)[nz] - e[nz]) / np.maximum(np.abs(e[nz]), floor)).mean())
-            o_fl, k_fl = fl(oracle), fl(xa)
-            assert o_fl <= ORACLE_OWN_CAP * tol, f"{name}: the ORACLE's own floored mean_rel {o_fl:.3e} exceeds {ORACLE_OWN_CAP} x {tol:.1e} - oracle drift?"
-            bound = min(max(tol, 2.0 * o_fl), 2.0 * ORACLE_OWN_CAP * tol)
-            row.update(rule="oracle-floor", oracle=o_raw, oracle_floored=o_fl, floored=k_fl, bound=bound)
-            assert k_fl <= bound, f"{name} mean_rel(floor {floor:.1e})={k_fl:.3e} > max({tol:.1e}, 2 x oracle's {o_fl:.3e}) raw={k_raw:.3e}"
-            return
-        assert o_raw <= ORACLE_OWN_CAP * tol, f"{name}: the ORACLE's own raw mean_rel {o_raw:.3e} exceeds {ORACLE_OWN_CAP} x {tol:.1e} - oracle drift?"
-        cap = 2.0 * ORACLE_OWN_CAP if (sk is not None and sk <= ORACLE_TINY_SK) else float(ORACLE_BOUND_CAP)
-        bound = min(max(tol, 2.0 * o_raw), cap * tol)
-        row.update(rule="oracle", oracle=o_raw, bound=bound)
-        assert k_raw <= bound, f"{name} raw mean_rel={k_raw:.3e} > max({tol:.1e}, 2 x oracle's {o_raw:.3e})"
+            row.update(zero_elements=int((~nz).sum()), max_abs_on_zero_elements=float(np.abs(xa[~nz]).max()))       # (bounded by assert_close's max_abs check)
+        tiny = sk is not None and sk <= ORACLE_TINY_SK
+        floor = max(REL_EPS, 0.01 * float(np.sqrt(np.mean(e * e)))) if tiny else REL_EPS
+        rel = lambda t: float((np.abs(t[nz] - e[nz]) / np.maximum(np.abs(e[nz]), floor)).mean()) if nz.any() else 0.0
+        o_v, k_v = rel(oa), rel(xa)
+        # the oracle may widen the bound only so far (ADVICE r3): an oracle that drifts past ORACLE_OWN_CAP x the plain tolerance fails here instead of silently
+        # loosening every bound derived from it
+        assert o_v <= ORACLE_OWN_CAP * tol, f"{name}: the ORACLE's own mean_rel {o_v:.3e} exceeds {ORACLE_OWN_CAP} x {tol:.1e} - oracle drift?"
+        bound = min(max(tol, 2.0 * o_v), float(ORACLE_OWN_CAP if tiny else ORACLE_BOUND_CAP) * tol)
+        row.update(rule="oracle", oracle=raw_mean_rel(oa[nz], e[nz]), oracle_asserted=o_v, asserted=k_v, bound=bound, floored_denominator=bool(tiny))
+        assert k_v <= bound, f"{name} mean_rel={k_v:.3e} > max({tol:.1e}, 2 x oracle's {o_v:.3e}) (sk={sk}{', denominators floored at %.1e' % floor if tiny else ''})"
     elif sk is not None and sk >= PLAIN_SK_MIN:
-        if k_raw > tol and oracle_fn is not None:
-            # rule "oracle-lazy" (round 5, the reference's varlen grid): the plain bound failed on a problem too large to run the C oracle on as a matter of
-            # course.  The raw metric has a heavy tail (ONE element whose expectation is ~1e-6 with an error of one P rounding, 1e-4, adds 100 / n to the mean:
-            # dV of lq 1025 / lk 288 / 6:1 heads / d 64 reads 1.33e-2 with 18432 elements), so the reference algorithm itself is asked: the caller's
-            # `oracle_fn` runs the C oracle (contract mode) on this one tensor and the "oracle" rule applies with its usual cap - max(plain, 2 x the oracle's own).
-            o = np.asarray(oracle_fn(), dtype=np.float64)
-            o_raw = raw_mean_rel(o, e)
-            assert o_raw <= ORACLE_OWN_CAP * tol, f"{name}: the ORACLE's own raw mean_rel {o_raw:.3e} exceeds {ORACLE_OWN_CAP} x {tol:.1e} - oracle drift?"
-            bound = min(max(tol, 2.0 * o_raw), float(ORACLE_BOUND_CAP) * tol)
-            row.update(rule="oracle-lazy", oracle=o_raw, bound=bound)
-            assert k_raw <= bound, f"{name} raw mean_rel={k_raw:.3e} > max({tol:.1e}, 2 x oracle's {o_raw:.3e}) (sk={sk}, oracle consulted after the plain bound failed)"
-            return
-        row.update(rule="plain", bound=tol)
+        k_raw = row["kernel"]
+        row.update(rule="plain", bound=tol, asserted=k_raw)
         assert k_raw <= tol, f"{name} PLAIN mean_rel={k_raw:.3e} > {tol:.1e} (sk={sk})"
     else:
         floor = max(REL_EPS, 0.01 * float(np.sqrt(np.mean(e * e))))
         m_rel = float((np.abs(xa - e) / np.maximum(np.abs(e), floor)).mean())
-        row.update(rule="floor", bound=tol, floored=m_rel)
-        assert m_rel <= tol, f"{name} mean_rel(floor {floor:.1e})={m_rel:.3e} > {tol:.1e} raw={k_raw:.3e}"
+        row.update(rule="floor", bound=tol, asserted=m_rel)
+        assert m_rel <= tol, f"{name} mean_rel(floor {floor:.1e})={m_rel:.3e} > {tol:.1e} raw={row['kernel']:.3e}"
 
 
-def assert_close(x, ref, dtype, name, scale=1.0, sk=None, oracle=None, exact=None, oracle_fn=None):
+def assert_close(x, ref, dtype, name, scale=1.0, sk=None, oracle=None, exact=None):
     """THE stated tolerance of this repo (DESIGN.md "Parity"): the reference's three bounds
     (max_abs 5e-3, mean_abs 2e-4, mean_rel 1e-2 for fp16; x8 for bf16), made magnitude-aware so they stay
     meaningful on the reference grid's degenerate shapes (e.g. sk = 1: dV sums 1024 N(0,1) terms,
@@ -182,7 +160,7 @@ def assert_close(x, ref, dtype, name, scale=1.0, sk=None, oracle=None, exact=Non
     mean |x| = 0.8 is 2e-4 by itself).  First GPU run with the unconditional form (profiles/r2_parity_margins_first_run.json):
     O and dQ met the plain bounds on every one of ~2400 cases; dK / dV exceeded them on 6 cases, all sq >> sk with GQA
     (e.g. lq = 1002, lk = 99, 6 q-heads per kv-head: |dV| ~ 0.8-16), by exactly one output ulp.
-    The worst raw metrics per test family go to MARGINS (-> gpurun_out/parity_margins.json).
+    The worst raw metrics per test family go to MARGINS (-> gpurun_out/parity_margins_<stamp>.json).
     Returns the raw reference-style metrics for logging."""
     xa = np.asarray(x, dtype=np.float64)
     assert np.isfinite(xa).all(), f"{name}: non-finite values"
@@ -206,7 +184,7 @@ def assert_close(x, ref, dtype, name, scale=1.0, sk=None, oracle=None, exact=Non
     assert m_max <= tol["max_abs"] * scale, f"{name} max_abs(excess over 1 ulp)={m_max:.3e} > {tol['max_abs'] * scale:.3e} raw={raw}"
     assert m_mean <= tol["mean_abs"] * scale, f"{name} mean_abs(excess over ulp/2)={m_mean:.3e} > {tol['mean_abs'] * scale:.3e} raw={raw}"
     e = ref if exact is None else round_like_output(exact, dtype).astype(np.float64)
-    check_mean_rel(xa, e, dtype, name, scale, sk, oracle, ref_unrounded if exact is None else exact, oracle_fn)
+    check_mean_rel(xa, e, dtype, name, scale, sk, oracle, ref_unrounded if exact is None else exact)
     return raw
 
 

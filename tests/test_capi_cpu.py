@@ -40,18 +40,33 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.lib().fa_kernel_name(0, 4, 8192, 8192, 32, 64, 0) == capi.lib().fa_kernel_name_dtype(0, 0, 4, 8192, 8192, 32, 64, 0)      # fa_kernel_name = fp16
     assert capi.lib().fa_kernel_name_dtype(0, 7, 4, 8192, 8192, 32, 64, 0) == b""
     assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dq16_kernel"
-    assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, True) == "fa_bwd_dq_kernel"
-    assert capi.kernel_name("dq", 4, 16384, 16384, 32, 128, True) == "fa_bwd_dq16_kernel"       # round 4: causal dQ from 2^28 pairs per head
-    assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 128, True) == "fa_fwd_pp16_kernel"          # round 4: causal forward from 2^24 (was 2^26)
-    assert capi.kernel_name("fwd", 4, 2048, 2048, 32, 128, True) == "fa_fwd_pp_kernel"
-    assert capi.kernel_name("fwd", 4, 3072, 3072, 32, 128, True) == "fa_fwd_pp16_kernel"          # round 5: causal forward from 2^23, ...
-    assert capi.kernel_name("fwd", 4, 1024, 1024, 32, 128, False) == "fa_fwd_pp16_kernel"         # ... non-causal from 2^20 (was 2^22)
+    # round 6: forward and dQ by how far the LAUNCH fills the chip (256 CUs assumed without a device): >= 1 workgroup of 256 query rows per CU, >= 2 under a causal mask
+    # (or 1 from 8k x 8k), and >= 2^20 pairs per head for the forward and causal dQ
+    assert capi.kernel_name("dq", 4, 8192, 8192, 32, 128, True) == "fa_bwd_dq16_kernel"           # 4096 workgroups (rounds 4-5: causal dQ from 2^28 pairs per head only)
+    assert capi.kernel_name("dq", 4, 16384, 16384, 32, 128, True) == "fa_bwd_dq16_kernel"
+    assert capi.kernel_name("dq", 1, 4096, 4096, 8, 128, False) == "fa_bwd_dq_kernel"             # 128 workgroups: the chip is half empty, the 32x32x16 kernel is 5 % ahead
+    assert capi.kernel_name("dq", 1, 8192, 8192, 8, 128, False) == "fa_bwd_dq16_kernel"           # 256
+    assert capi.kernel_name("dq", 1, 8192, 8192, 8, 128, True) == "fa_bwd_dq_kernel"              # 256 under a mask: not yet
+    assert capi.kernel_name("dq", 1, 4096, 4096, 32, 128, True) == "fa_bwd_dq16_kernel"           # 512
+    assert capi.kernel_name("dq", 64, 512, 512, 32, 128, True) == "fa_bwd_dq_kernel"              # many workgroups, but 2^18 pairs per head
+    assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 128, True) == "fa_fwd_pp16_kernel"
+    assert capi.kernel_name("fwd", 4, 2048, 2048, 32, 128, True) == "fa_fwd_pp16_kernel"          # 1024 workgroups (round 5: from 2^23 pairs per head)
+    assert capi.kernel_name("fwd", 4, 1024, 1024, 32, 128, False) == "fa_fwd_pp16_kernel"         # 512
+    assert capi.kernel_name("fwd", 1, 1024, 1024, 32, 128, False) == "fa_fwd_pp_kernel"           # 128 workgroups
+    assert capi.kernel_name("fwd", 1, 2048, 2048, 32, 128, False) == "fa_fwd_pp16_kernel"         # 256
+    assert capi.kernel_name("fwd", 1, 2048, 2048, 32, 128, True) == "fa_fwd_pp_kernel"            # 256 under a mask
+    assert capi.kernel_name("fwd", 1, 8192, 8192, 8, 128, True) == "fa_fwd_pp16_kernel"           # 256 under a mask, 2^26 pairs
+    assert capi.kernel_name("fwd", 64, 512, 512, 32, 128, False) == "fa_fwd_pp_kernel"            # 2^18 pairs per head
     assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 128, False) == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dkdv", 4, 512, 512, 32, 128, True) == "fa_bwd_dkdv_kernel"
-    # per head, not per launch: a (batch, head) shard gets the kernel of the whole problem
-    assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == capi.kernel_name("fwd", 64, 16384, 16384, 64, 128, True) == "fa_fwd_pp16_kernel"
-    assert capi.kernel_name("dkdv", 1, 8192, 8192, 2, 128, True) == "fa_bwd_dkdv16_kernel"
+    # per launch (round 6) - unless the caller states the whole problem's batch x heads: a (batch, head) shard then gets the kernel of the whole problem
+    assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == "fa_fwd_pp_kernel" and capi.kernel_name("fwd", 64, 16384, 16384, 64, 128, True) == "fa_fwd_pp16_kernel"
+    assert capi.set_policy_problem_heads(64 * 64) == 0
+    assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == "fa_fwd_pp16_kernel" and capi.kernel_name("dq", 1, 16384, 16384, 1, 128, True) == "fa_bwd_dq16_kernel"
+    assert capi.set_policy_problem_heads(0) == 64 * 64 and capi.lib().fa_set_policy_problem_heads(-5) == -1 and capi.set_policy_problem_heads(0) == 0
+    assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("dkdv", 1, 8192, 8192, 2, 128, True) == "fa_bwd_dkdv16_kernel"       # dK/dV: by the pairs per head whatever the launch
     # head_dim 64 backward (round 5): dQ 16x16x32 without a mask at every length and under one from 2^26 pairs per head; dK/dV from 2^24 (2^28 causal);
     # never when a causal problem has fewer keys than queries (dead row blocks); both dtypes
     assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, False) == capi.kernel_name("dkdv", 1, 4096, 4096, 1, 64, False, "bf16") == "fa_bwd_dkdv16_kernel"

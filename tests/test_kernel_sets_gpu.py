@@ -1,11 +1,8 @@
 """GPU: both head_dim-128 kernel sets (v_mfma_f32_32x32x16 and v_mfma_f32_16x16x32 tiles) over the whole test grid.
 
-Under the default policy the forward and dK/dV pick by seqlen_q * seqlen_k and dQ by the mask (include/flash_attn_gfx950.h,
-fa_set_kernel_policy), so the rest of the suite reaches fa_fwd_pp16.hip / fa_bwd_dkdv16.hip only in the full-size tests and the 32x32x16
-dQ at head_dim 128 only under a causal mask.  Every test below runs twice: pinned to the 16x16x32 set and pinned to the 32x32x16 set.
-
-The launcher gives the 16x16x32 forward the large problems only (seqlen_q * seqlen_k >= 2^22 per head, 2^24 under a causal mask; dK/dV from 2^20; dQ without
-a mask, under one from 2^28: include/flash_attn_gfx950.h, fa_set_kernel_policy), so
+Under the default policy the head_dim-128 forward and dQ go to the 16x16x32 set only when the launch fills the chip (at least one 256-row workgroup per compute unit,
+two under a causal mask) and dK/dV from 2^20 (query, key) pairs per head (include/flash_attn_gfx950.h, fa_set_kernel_policy - the thresholds live THERE and in
+`capi.kernel_name`, which the asserts below ask; they are not restated here), so
 of the suite only the full-size value-parity and property tests reach it on their own.  This module pins the policy to that kernel
 and runs the forward-facing tests of the other modules again at head_dim 128: the golden vectors, the C-oracle cases, the
 reference's (sq, sk) grid, packed sequences, the softmax edge cases - every tail, mask and head-group path of the kernel.  It also

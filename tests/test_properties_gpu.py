@@ -91,8 +91,9 @@ def test_linearity_in_v_and_in_dout(gpu):
 def test_batch_head_sharding_equals_whole_and_is_deterministic(gpu, causal, s, hk):
     """The multi-GPU decomposition (independent (batch, head) problems, strided shard views) gives
     bit-identical results to the unsharded call - forward and backward, also at the sizes where head_dim 128 switches
-    kernel sets (the choice is per head, never per launch: include/flash_attn_gfx950.h, fa_set_kernel_policy) - and
-    repeated calls are bit-identical.  dK / dV of a GQA group are the one exception: how many workgroups share a group's query heads
+    kernel sets: since round 6 the choice follows how far the LAUNCH fills the chip, so the shards run under `problem_policy(batch, heads)`, which states the
+    whole problem's size to the policy (include/flash_attn_gfx950.h, fa_set_policy_problem_heads); the test also checks that the whole problem and a lone shard
+    WOULD be served by different kernels somewhere on this grid (otherwise it proves nothing) - and repeated calls are bit-identical.  dK / dV of a GQA group are the one exception: how many workgroups share a group's query heads
     (the fp32 workspace split, C ABI 3) depends on how full the launch would leave the chip, so a shard may sum the same products in another
     order; there they agree to a rounding of the output format."""
     import flash_attn_turing as F
@@ -104,14 +105,34 @@ def test_batch_head_sharding_equals_whole_and_is_deterministic(gpu, causal, s, h
     o_again, lse_again = F.fwd(q, k, v, causal)
     assert torch.equal(o, o_again) and torch.equal(lse, lse_again)
     dq, dk, dv = F.bwd(q, k, v, o, lse, do, causal)
-    for plan in F.plan_shards(b, h, hk, 8):
+    plans = F.plan_shards(b, h, hk, 8)
+    sb, sh = plans[0].batch_stop - plans[0].batch_start, plans[0].head_stop - plans[0].head_start
+    _SHARD_KERNELS_DIFFER.append(any(F.kernel_name(st, b, s, s, h, d, causal) != F.kernel_name(st, sb, s, s, sh, d, causal) for st in ("fwd", "dq")))
+    with F.problem_policy(b, h):
+        assert all(F.kernel_name(st, b, s, s, h, d, causal) == F.kernel_name(st, sb, s, s, sh, d, causal) for st in ("fwd", "dq", "dkdv"))
+        _check_shards(F, plans, q, k, v, do, o, lse, dq, dk, dv, causal, hk == h)
+    from flash_attn_turing import capi
+
+    assert capi.set_policy_problem_heads(0) == 0          # restored
+
+
+_SHARD_KERNELS_DIFFER = []
+
+
+def test_sharding_grid_above_crosses_a_policy_boundary():
+    """(runs after the parametrised test above) at least one of its cases must be one where a lone shard and the whole problem get different kernel sets"""
+    assert _SHARD_KERNELS_DIFFER and any(_SHARD_KERNELS_DIFFER)
+
+
+def _check_shards(F, plans, q, k, v, do, o, lse, dq, dk, dv, causal, mha):
+    for plan in plans:
         qs, ks, vs, dos = F.shard_tensor(q, plan, False), F.shard_tensor(k, plan, True), F.shard_tensor(v, plan, True), F.shard_tensor(do, plan, False)
         os_, ls_ = F.fwd(qs, ks, vs, causal)
         assert torch.equal(os_, F.shard_tensor(o, plan, False))
         assert torch.equal(ls_, lse[plan.batch_start:plan.batch_stop, plan.head_start:plan.head_stop])
         dqs, dks, dvs = F.bwd(qs, ks, vs, os_, ls_, dos, causal)
         assert torch.equal(dqs, F.shard_tensor(dq, plan, False))
-        if hk == h:
+        if mha:
             assert torch.equal(dks, F.shard_tensor(dk, plan, True)) and torch.equal(dvs, F.shard_tensor(dv, plan, True))
         else:
             for got, whole in ((dks, F.shard_tensor(dk, plan, True)), (dvs, F.shard_tensor(dv, plan, True))):

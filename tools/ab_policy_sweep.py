@@ -11,6 +11,7 @@ ap.add_argument("--b", type=int, default=4); ap.add_argument("--h", type=int, de
 ap.add_argument("--d", type=int, default=128); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--seqs", default="1024,2048,4096,8192,16384")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+worst = 1.0
 for causal in (False, True):
     for s in (int(x) for x in a.seqs.split(",")):
         g = torch.Generator(device=dev).manual_seed(s)
@@ -35,6 +36,9 @@ for causal in (False, True):
                     e1.record(); e1.synchronize(); t[pol].append(e0.elapsed_time(e1) / iters)
             m32, m16 = statistics.median(t[0]), statistics.median(t[1])
             pick16 = "16" in auto[st]
-            row.append(f"{st} 32x32 {m32:8.3f} ms 16x16 {m16:8.3f} ms ({m16 / m32:5.3f}) auto->{'16' if pick16 else '32'}{'' if (m16 < m32) == pick16 or abs(m16 / m32 - 1) < 0.01 else ' (!)'}")
+            r_auto = (m16 if pick16 else m32) / min(m16, m32)      # ratio_auto_over_best_pinned: AUTO launches exactly the kernel of the set it picks
+            worst = max(worst, r_auto)
+            row.append(f"{st} 32x32 {m32:8.3f} ms 16x16 {m16:8.3f} ms ({m16 / m32:5.3f}) auto->{'16' if pick16 else '32'} auto/best {r_auto:5.3f}{'' if r_auto <= 1.03 else ' (!)'}")
         print(f"b{a.b} h{a.h} s{s:6d} {a.dtype} causal={int(causal)} | " + " | ".join(row), flush=True)
 capi.set_kernel_policy(capi.POLICY_AUTO)
+print(f"# b{a.b} h{a.h} d{a.d} {a.dtype}: worst ratio_auto_over_best_pinned {worst:5.3f}  ('(!)' = above 1.03)")

@@ -157,6 +157,84 @@ __global__ void k_bench(unsigned long long* out, float seed) {
     if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;
 }
 
+
+// ---- round 6: the cadence of v_mfma_f32_16x16x32 issued by ONE wave -------------------------------------------------------------------
+//   A wave's stream: NACC independent accumulators (inline asm, in place, like the kernels), and per PAIR of MFMAs one of
+//   C_NONE nothing, C_B128 one ds_read_b128 (never waited on), C_B128W the same + s_waitcnt lgkmcnt(1), C_TRW two ds_read_b64_tr_b16 + s_waitcnt lgkmcnt(2)
+//   (the forward's P.V fragment step as hipcc emits it), C_NOP one s_nop 0, C_TR2W = C_TRW with ONE wait per two pairs, C_SOFTMAX = no MFMAs: 3 VALU of the softmax mix per "pair".
+// The figure printed is cycles per MFMA (16 = the pipe's rate); for C_SOFTMAX cycles per VALU instruction.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+enum { C_NONE, C_B128, C_B128W, C_TRW, C_NOP, C_TR2W, C_SOFTMAX, C_IDLE, C_FMA, C_PKFMA, C_EXP, C_CVT, C_SOFTMAX_PK };
+template <int NACC, int KIND, bool AGPR>
+__device__ __forceinline__ void cad_stream(f32x4_ (&c)[16], float (&r)[16], u32x4_& fr, unsigned int la, f16x8 a, f16x8 b, int iters) {
+    if constexpr (KIND == C_IDLE) return;
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (KIND == C_FMA || KIND == C_PKFMA || KIND == C_EXP || KIND == C_CVT || KIND == C_SOFTMAX_PK) {
+            // single-instruction streams, and the softmax mix with PACKED multiply-subtracts: per 16 instructions 4 v_pk_fma_f32 (= 8 scores), 8 v_exp_f32, 4 v_cvt_pk
+            // (the work of 20 instructions of the scalar mix)
+#define X(i)                                                                                                                        \
+            if (KIND == C_FMA) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(r[i]));                                                  \
+            else if (KIND == C_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));                                                   \
+            else if (KIND == C_CVT) asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(r[i]));                                        \
+            else if (KIND == C_PKFMA || (i) % 4 == 0) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*(f32x2*)&r[((i) & 7) * 2]));     \
+            else if ((i) % 4 == 3) asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(r[i]));                                         \
+            else asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+            REP16(X)
+#undef X
+        } else if constexpr (KIND == C_SOFTMAX) {
+#define X(i)                                                                                                    \
+            if ((i) % 3 == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(r[i]));                             \
+            else if ((i) % 3 == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));                               \
+            else if ((i) == 5) asm volatile("v_pk_maximum3_f16 %0, %0, %0, %0" : "+v"(r[i]));                    \
+            else asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(r[i]));
+            REP16(X)
+#undef X
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c[i % NACC]) : "v"(a), "v"(b));
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c[i % NACC]) : "v"(a), "v"(b));
+                if (i & 1) {
+                    if constexpr (KIND == C_B128) asm volatile("ds_read_b128 %0, %1" : "=v"(fr) : "v"(la));
+                    if constexpr (KIND == C_B128W) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(1)" : "=v"(fr) : "v"(la));
+                    if constexpr (KIND == C_TRW || KIND == C_TR2W) {
+                        unsigned long long t0_, t1_;
+                        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=v"(t0_), "=v"(t1_) : "v"(la));
+                        if (KIND == C_TRW || (i & 2)) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        fr[0] = (unsigned int)t0_; fr[2] = (unsigned int)t1_;
+                    }
+                    if constexpr (KIND == C_NOP) asm volatile("s_nop 0");
+                }
+            }
+        }
+    }
+}
+template <int NA, int KA, bool AGA, int NB, int KB, int PA, int PB>
+__global__ void k_cad(unsigned long long* out, float seed) {
+    __shared__ unsigned int lds_[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds_[i] = 0x3c003c00u;
+    f32x4_ c[16];
+    float r[16];
+    f16x8 a, b;
+    for (int i = 0; i < 16; ++i) { r[i] = seed + threadIdx.x * 1e-3f + i; c[i] = f32x4_{r[i], r[i], r[i], r[i]}; }
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(seed + i); b[i] = (_Float16)(seed - i); }
+    u32x4_ fr = {0, 0, 0, 0};
+    const unsigned int la = (unsigned int)(size_t)lds_ + (threadIdx.x & 63) * 16;
+    const int wave = threadIdx.x >> 6;
+    if (wave < 4) __builtin_amdgcn_s_setprio(PA); else __builtin_amdgcn_s_setprio(PB);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    if (wave < 4) cad_stream<NA, KA, AGA>(c, r, fr, la, a, b, ITERS);
+    else cad_stream<NB, KB, false>(c, r, fr, la, a, b, ITERS);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    float sink = __builtin_bit_cast(float, fr[0]) + __builtin_bit_cast(float, fr[2]);
+    for (int i = 0; i < 16; ++i) { if constexpr (AGA) asm volatile("" : "+a"(c[i])); else asm volatile("" : "+v"(c[i])); sink += r[i] + c[i][0] + c[i][3]; }
+    if (sink == 12345.678f) out[100] = 1;
+    if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int TA, int TB, int PA = 0, int PB = 0>
@@ -170,6 +248,19 @@ void run(unsigned long long* d, int threads, const char* label) {
     const double n = (double)ITERS * 16;
     if (threads == 256) printf("%-44s alone: %6.2f cyc/instr/wave\n", label, h[0] / n);
     else printf("%-44s A: %6.2f cyc/instr   B: %6.2f cyc/instr (waves 0 and 4 share SIMD0)\n", label, h[0] / n, h[4] / n);
+}
+
+template <int NA, int KA, bool AGA, int NB, int KB, int PA = 0, int PB = 0>
+void run_cad(unsigned long long* d, int threads, const char* label) {
+    unsigned long long h[8];
+    for (int rep = 0; rep < 2; ++rep) {
+        k_cad<NA, KA, AGA, NB, KB, PA, PB><<<1, threads>>>(d, 1.0f);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    const double n = (double)ITERS * 16;
+    if (threads == 256) printf("%-64s alone: %6.2f cyc per MFMA (or VALU)\n", label, h[0] / n);
+    else printf("%-64s A: %6.2f   B: %6.2f  cyc per MFMA / VALU (waves 0 and 4 share SIMD0)\n", label, h[0] / n, h[4] / n);
 }
 
 int main() {
@@ -225,6 +316,44 @@ int main() {
     run<T_MN7, T_MIX_EXP_FMA>(d, 512, "mfma+s_nop 7 | exp+fma");
     run<T_MN5, T_MN5>(d, 256, "mfma+s_nop 5 alone");
     run<T_MN6, T_MN6>(d, 256, "mfma+s_nop 6 alone");
+    printf("== round 6: cadence of v_mfma_f32_16x16x32 from ONE wave per SIMD (cycles per MFMA; the pipe needs 16) ==\n");
+    run_cad<2, C_NONE, false, 8, C_IDLE>(d, 256, "mfma16, 2 accumulators");
+    run_cad<4, C_NONE, false, 8, C_IDLE>(d, 256, "mfma16, 4 accumulators");
+    run_cad<8, C_NONE, false, 8, C_IDLE>(d, 256, "mfma16, 8 accumulators");
+    run_cad<16, C_NONE, false, 8, C_IDLE>(d, 256, "mfma16, 16 accumulators");
+    run_cad<8, C_NONE, true, 8, C_IDLE>(d, 256, "mfma16, 8 accumulators in AGPRs");
+    run_cad<8, C_B128, false, 8, C_IDLE>(d, 256, "mfma16 8 acc + ds_read_b128 per pair");
+    run_cad<8, C_B128W, false, 8, C_IDLE>(d, 256, "mfma16 8 acc + (ds_read_b128 + s_waitcnt) per pair");
+    run_cad<8, C_TRW, false, 8, C_IDLE>(d, 256, "mfma16 8 acc + (2 ds_read_tr + s_waitcnt) per pair");
+    run_cad<8, C_TR2W, false, 8, C_IDLE>(d, 256, "mfma16 8 acc + 2 ds_read_tr per pair, one s_waitcnt per 2 pairs");
+    run_cad<8, C_NOP, false, 8, C_IDLE>(d, 256, "mfma16 8 acc + s_nop 0 per pair");
+    run_cad<8, C_SOFTMAX, false, 8, C_IDLE>(d, 256, "softmax VALU mix (fma, exp, cvt / max3)");
+    printf("== round 6: the MFMA wave (A) sharing its SIMD with a softmax-mix wave (B) ==\n");
+    run_cad<8, C_NONE, false, 8, C_SOFTMAX>(d, 512, "mfma16 | softmax mix");
+    run_cad<8, C_NONE, false, 8, C_SOFTMAX, 1, 0>(d, 512, "mfma16 (p1) | softmax mix (p0)");
+    run_cad<8, C_NONE, false, 8, C_SOFTMAX, 0, 1>(d, 512, "mfma16 (p0) | softmax mix (p1)");
+    run_cad<8, C_NONE, false, 8, C_SOFTMAX, 3, 0>(d, 512, "mfma16 (p3) | softmax mix (p0)");
+    run_cad<8, C_NONE, true, 8, C_SOFTMAX>(d, 512, "mfma16 AGPR | softmax mix");
+    run_cad<8, C_B128W, false, 8, C_SOFTMAX>(d, 512, "mfma16 + (b128 + wait) per pair | softmax mix");
+    run_cad<8, C_TRW, false, 8, C_SOFTMAX>(d, 512, "mfma16 + (2 tr + wait) per pair | softmax mix");
+    run_cad<8, C_TRW, false, 8, C_SOFTMAX, 1, 0>(d, 512, "mfma16 + (2 tr + wait) per pair (p1) | softmax mix (p0)");
+    run_cad<8, C_TR2W, false, 8, C_SOFTMAX>(d, 512, "mfma16 + 2 tr per pair, wait per 2 pairs | softmax mix");
+    run_cad<8, C_SOFTMAX, false, 8, C_TRW>(d, 512, "softmax mix | mfma16 + (2 tr + wait) per pair  [VALU wave older]");
+    run_cad<8, C_FMA, false, 8, C_IDLE>(d, 256, "v_fma_f32 stream");
+    run_cad<8, C_PKFMA, false, 8, C_IDLE>(d, 256, "v_pk_fma_f32 stream");
+    run_cad<8, C_EXP, false, 8, C_IDLE>(d, 256, "v_exp_f32 stream");
+    run_cad<8, C_SOFTMAX_PK, false, 8, C_IDLE>(d, 256, "softmax mix with packed fma (4 pk_fma, 8 exp, 4 cvt)");
+    run_cad<8, C_NONE, false, 8, C_FMA>(d, 512, "mfma16 | v_fma_f32");
+    run_cad<8, C_NONE, false, 8, C_PKFMA>(d, 512, "mfma16 | v_pk_fma_f32");
+    run_cad<8, C_NONE, false, 8, C_EXP>(d, 512, "mfma16 | v_exp_f32");
+    run_cad<8, C_NONE, false, 8, C_CVT>(d, 512, "mfma16 | v_cvt_pk_f16_f32");
+    run_cad<8, C_NONE, false, 8, C_SOFTMAX_PK>(d, 512, "mfma16 | softmax mix with packed fma");
+    run_cad<8, C_TRW, false, 8, C_FMA>(d, 512, "mfma16 + (2 tr + wait) per pair | v_fma_f32");
+    run_cad<8, C_TRW, false, 8, C_PKFMA>(d, 512, "mfma16 + (2 tr + wait) per pair | v_pk_fma_f32");
+    run_cad<8, C_TRW, false, 8, C_EXP>(d, 512, "mfma16 + (2 tr + wait) per pair | v_exp_f32");
+    run_cad<8, C_TRW, false, 8, C_SOFTMAX_PK>(d, 512, "mfma16 + (2 tr + wait) per pair | softmax mix with packed fma");
+    run_cad<8, C_NONE, false, 8, C_NONE>(d, 512, "mfma16 | mfma16");
+    run_cad<8, C_TRW, false, 8, C_TRW>(d, 512, "mfma16 + (2 tr + wait) | the same");
     printf("== priorities (A prio, B prio) ==\n");
     run<T_MFMA, T_FMA, 0, 1>(d, 512, "mfma(p0) | fma(p1)");
     run<T_MFMA, T_FMA, 0, 3>(d, 512, "mfma(p0) | fma(p3)");
