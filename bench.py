@@ -205,7 +205,7 @@ def strong_scaling_sweep(dist, make_point, sync_fn, device, seqs=SWEEP_SEQS, cau
                 # batch x heads): its results are bit-identical to the unsharded call's, tests/test_properties_gpu.py
                 with problem_policy(b, h):
                     f()
-            iters = 20 if seq <= 4096 else 6
+            iters = 20      # (round 6: also at 8k / 16k, where 6 launches were a 40 ms window - shorter than the clock's settling time, 1-3 % optimistic against the headline's 20)
             flops = fwd_flops(b, seq, seq, h, d, causal)
             single = None
             if dist.rank == 0:
@@ -448,28 +448,39 @@ def parse_clockbench_rows(out):
     return rows
 
 
+PROBE_MIX_D128 = "16x16x32 mix: 3.1 VALU + 1 KiB LDS (fwd d128 now), 2 w/SIMD"
+PROBE_PP_D128 = "16x16x32 ping-pong d128: 68 MFMA + 48 LDS | 95 VALU, 8 waves"
+PROBE_MIX_D64 = "16x16x32 mix: 5.2 VALU + 1 KiB LDS (fwd d64), 2 w/SIMD"
+PROBE_PP_D64 = "16x16x32 ping-pong d64: 68 MFMA + 48 LDS | 190 VALU, 8 waves"
+PROBE_PURE16 = "16x16x32 MFMA only, 2 waves/SIMD"
+
+
 def ceiling_block(workload, kernel, achieved, clock_rows):
-    """`roofline.ceiling`: the distance between `achieved` and the nominal 2.5 PFLOP/s, decomposed in the line itself.
-      nominal peak  ->  what a chip-wide loop of NOTHING BUT this kernel's MFMA instruction sustains on N(0,1) operands under the package power cap
-                        (tools/clockbench in this run: the matrix pipes 100 % busy, the clock the SMU grants)
-                    ->  what THIS kernel's structure reaches with its LDS fragment reads, exponentials and LDS-DMA compiled out (timing-only ablation
-                        builds, results wrong by construction; newest committed profiles/rNN_fwd_ceiling_ablations.json: a time ratio against the
-                        shipped kernel, A/B-interleaved on one box)
+    """`roofline.ceiling`: the distance between `achieved` and the nominal 2.5 PFLOP/s, decomposed in the line itself, every step measured IN THIS RUN with the kernel's
+    own MFMA shape (until round 5 the mixed rows were v_mfma_f32_32x32x16 loops beside a 16x16x32 kernel):
+      nominal peak  ->  a chip-wide loop of NOTHING BUT this kernel's MFMA instruction on N(0,1) operands (the package power cap)
+                    ->  the kernel's own STRUCTURE without its dependencies (tools/clockbench k_pp16: eight waves in two groups one phase apart, matrix phase = 68 MFMAs
+                        + 48 LDS fragment reads at prefetch depth 2 whose data are the MFMAs' operands, softmax phase = 95 VALU in the softmax's composition, two
+                        barriers per tile; no LDS-DMA, no mask, no data dependence between the phases, no prologue / epilogue)
                     ->  achieved.
-    Each step names what it contains; none of them is ever used as `peak`."""
+    Beside the chain: the same instruction mix as ONE interleaved stream per wave (k_mix16, 3.1 VALU + 1 KiB of LDS reads per 32768 FLOP) - the probe the round-3..5
+    statements quoted in its 32x32x16 form - and the timing-only ablation builds of the kernel itself (newest committed profile).  None of them is ever used as `peak`."""
     import glob
     import re
 
     out = {"what": "decomposition of achieved / peak; measured rates under the power cap, never used as `peak`", "nominal_peak_tflops": PEAK_DENSE_FP16_TFLOPS,
            "shipped_tflops": achieved}
-    own = "16x16x32 MFMA only, 2 waves/SIMD" if "16" in kernel else "MFMA only, 2 waves/SIMD"
+    is16 = "16" in kernel
+    own = PROBE_PURE16 if is16 else "MFMA only, 2 waves/SIMD"
     if clock_rows:
-        out["pure_mfma_on_n01_operands_tflops"] = {"this_kernels_mfma_shape": clock_rows.get(own), "shape": "v_mfma_f32_16x16x32" if "16" in kernel else "v_mfma_f32_32x32x16",
-                                                  "v_mfma_f32_32x32x16": clock_rows.get("MFMA only, 2 waves/SIMD"), "v_mfma_f32_16x16x32": clock_rows.get("16x16x32 MFMA only, 2 waves/SIMD"),
+        out["pure_mfma_on_n01_operands_tflops"] = {"this_kernels_mfma_shape": clock_rows.get(own), "shape": "v_mfma_f32_16x16x32" if is16 else "v_mfma_f32_32x32x16",
+                                                  "v_mfma_f32_32x32x16": clock_rows.get("MFMA only, 2 waves/SIMD"), "v_mfma_f32_16x16x32": clock_rows.get(PROBE_PURE16),
                                                   "source": "tools/clockbench in this run (median of 5 interleaved chip-wide runs, random operands)"}
         out["instruction_mix_probe_tflops"] = {k: v for k, v in clock_rows.items() if "VALU" in k or "LDS" in k}
-        out["instruction_mix_probe_note"] = ("dependency-free chip-wide loops of 32x32x16 MFMAs with the forward's own VALU / LDS-read density per MFMA "
-                                             "(4 VALU + 1 KiB): what an ideal schedule of that mix sustains, relative to the `MFMA only` row of the same probe")
+        out["instruction_mix_probe_note"] = ("chip-wide loops, median of 5 interleaved runs in this run.  Rows '16x16x32 mix': v_mfma_f32_16x16x32_f16 whose A operands are "
+                                             "the LDS reads' data, VALU in the softmax's composition (fma, exp, cvt_pk, pk_max3) at the density named, one interleaved stream per "
+                                             "wave.  Rows '16x16x32 ping-pong': the forward's two-group structure with the instruction counts of one tile per phase.  Rows 'MFMA + ...': "
+                                             "the round-1 probe (v_mfma_f32_32x32x16, constant operands), kept for comparison across rounds")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fwd_ceiling_ablations.json")), key=lambda p: int(re.search(r"r(\d+)_", os.path.basename(p)).group(1)))
     abl = None
     for path in reversed(files):
@@ -486,32 +497,54 @@ def ceiling_block(workload, kernel, achieved, clock_rows):
         out["same_structure_ablated"] = {"source": f"committed profile {name} (timing-only ablation builds, not measured in this run)", "library_source_digest": d.get("library_source_digest"),
                                          "time_ratio_vs_shipped": w["time_ratio_vs_shipped"],
                                          "tflops_scaled_to_this_run": {k: achieved / v for k, v in w["time_ratio_vs_shipped"].items() if v}}
-    pm = (out.get("pure_mfma_on_n01_operands_tflops") or {}).get("this_kernels_mfma_shape")
-    allab = (out.get("same_structure_ablated") or {}).get("tflops_scaled_to_this_run", {}).get("no_lds_reads_no_exp_no_dma")
+    rows = clock_rows or {}
+    pm = rows.get(own)
+    d64 = "d64" in workload
+    structure, mix = (rows.get(PROBE_PP_D64 if d64 else PROBE_PP_D128), rows.get(PROBE_MIX_D64 if d64 else PROBE_MIX_D128)) if is16 else (None, None)
     chain = [["nominal dense fp16 MFMA peak (256 CUs x 2.4 GHz x 4096 FLOP/clk)", PEAK_DENSE_FP16_TFLOPS]]
     if pm:
         chain.append(["power cap: this MFMA shape alone, pipes 100 % busy, N(0,1) operands", pm])
-    if allab:
-        chain.append(["this kernel's structure with LDS fragment reads, exponentials and LDS-DMA removed (8-wave ping-pong, barriers, issue coupling, causal diagonal, "
-                      "prologue / epilogue, row maxima and conversions remain)", allab])
-    chain.append(["shipped kernel (adds back: LDS operand reads, v_exp_f32, LDS-DMA issue)", achieved])
+    if structure:
+        chain.append(["this kernel's structure and instruction counts without its dependencies (two-group ping-pong probe: no LDS-DMA, no mask, no causal diagonal, "
+                      "no prologue / epilogue, straight-line softmax)", structure])
+    chain.append(["shipped kernel", achieved])
     out["chain_tflops"] = chain
     out["chain_step_ratios"] = [chain[i + 1][1] / chain[i][1] for i in range(len(chain) - 1)]
     out["frac_of_power_capped_mfma_rate"] = achieved / pm if pm else None
+    out["shipped_over_structure_probe"] = achieved / structure if structure else None
+    out["shipped_over_mixed_stream_probe"] = achieved / mix if mix else None
+    out["mixed_stream_probe_tflops"] = mix
     return out
+
+
+def run_clockbench(argv, timeout=240):
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "clockbench")
+    if not os.path.exists(exe):
+        return None
+    return subprocess.run([exe] + list(argv), capture_output=True, text=True, timeout=timeout).stdout
+
+
+def power_capped_mfma_rate(seconds=1.0):
+    """the denominator of `frac_of_power_capped_mfma_rate`, at SETTLED power: ONE launch of the chip-wide v_mfma_f32_16x16x32 loop lasting >= `seconds`
+    (tools/clockbench --rows ... --seconds: VERDICT r5 item 7 - the 25 ms launches of the full table read the first moments of a load step)"""
+    try:
+        text = run_clockbench(["--rows", PROBE_PURE16, "--seconds", str(seconds), "--reps", "1"])
+        rows = parse_clockbench_rows(text or "")
+        return rows.get(PROBE_PURE16)
+    except Exception:  # noqa: BLE001 - the line reports None
+        return None
 
 
 def measured_mfma_ceiling():
     """tools/clockbench (built by __graft_entry__.build()): TFLOP/s of a chip-wide back-to-back MFMA loop on random operands
     = what the MFMA roof really is on this box under its power limit (median of 5 interleaved runs).  Reported next to the
     nominal 2.5 PFLOP/s, never used as `peak`."""
-    import subprocess
-
-    exe = os.path.join(ROOT, "tools", "clockbench")
-    if not os.path.exists(exe):
-        return {"error": "tools/clockbench not built"}
     try:
-        text = subprocess.run([exe], capture_output=True, text=True, timeout=180).stdout
+        text = run_clockbench([])
+        if text is None:
+            return {"error": "tools/clockbench not built"}
         res = parse_clockbench(text)
         res["rows"] = parse_clockbench_rows(text)
         return res
@@ -677,6 +710,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--fake-step", action="store_true", help="CPU-only harness self-test (no kernels)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--n1-consistency", action="store_true", help="with --no-extra: still run the N = 1 row of the strong-scaling sweep beside the headline (extra.n1_consistency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seq", type=int, default=4096)
     args = ap.parse_args()
@@ -719,6 +753,8 @@ def main():
 
     sync = lambda: torch.cuda.synchronize(device)
     flops_rank = fwd_flops(b, s, s, h, d, causal) * (3.5 if backward else 1.0)
+    # the power-capped MFMA rate of this box, >= 1 s at settled power, BEFORE the timed region (and again after it, below): the box-independent denominator
+    pm_before = power_capped_mfma_rate() if (dist.rank == 0 and dist.world == 1 and not args.no_extra) else None
     region_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     with PowerSampler(device.index) as sampler:
         wall, _ = timed_region(step, args.steps, args.warmup, dist, sync, device, events=region_events)
@@ -778,25 +814,56 @@ def main():
                                     "cus_x_sclk_x_4096_tflops": prop.multi_processor_count * sclk_ghz * MFMA_FLOP_PER_CLK_PER_CU / 1e3}}
 
     extra = {}
+    state = {}
+
+    def make_point(seq, cz, plan):
+        # whole tensors on every rank (same seed), the rank's shard = strided views of them (no copy)
+        if state.get("seq") != seq:
+            state.clear()
+            torch.cuda.empty_cache()
+            w = make_inputs(torch, device, 4, seq, 32, 32, 128, "fp16", 99, False)
+            qs, os_ = shard_tensor(w["q"], plan, False), shard_tensor(w["o"], plan, False)
+            ks, vs = shard_tensor(w["k"], plan, True), shard_tensor(w["v"], plan, True)
+            lse_s = torch.empty(qs.shape[0], qs.shape[2], seq, device=device, dtype=torch.float32)
+            state.update(seq=seq, w=w, shard=(qs, ks, vs, os_, lse_s))
+        w, (qs, ks, vs, os_, lse_s) = state["w"], state["shard"]
+        ps = capi.fwd_params(qs, ks, vs, os_, lse_s, cz) if qs.numel() else None
+        pw = capi.fwd_params(w["q"], w["k"], w["v"], w["o"], w["lse"], cz)
+        return (lambda: capi.run_fwd(ps) if ps is not None else None), (lambda: capi.run_fwd(pw))
+
+    if args.workload == "c3" and dist.world == 1 and (args.n1_consistency or not args.no_extra):
+        # N = 1 consistency: the driver derives scaling efficiency from the headline `value` of its N = 1, 2, 4, 8 runs, the line's own strong-scaling
+        # sweep from its in-run single-GPU reference.  At N = 1 the shard IS the whole problem and the sweep's 16k-causal point is the headline workload through the OTHER code
+        # path (plan_shards -> shard views -> run_fwd on prepared params under the whole problem's policy): the two must tell the same rate, or the first real SCALE run would
+        # debut a harness discrepancy together with RCCL.  Two consecutive 0.14 s windows on this chip differ by up to 4 % whatever they run (the clock follows the package
+        # power, which follows the last second's history), so the three step functions are timed INTERLEAVED, 4 rounds x 40 launches each between the same barrier + sync
+        # brackets, and compared by their medians.  tests/test_perf_relations_gpu.py asserts 1 %.
+        from flash_attn_turing.sharding import plan_shards, problem_policy
+        import statistics as _st
+
+        step_shard_own, step_whole = make_point(s, causal, plan_shards(4, 32, 32, 1)[0])
+
+        def step_shard():
+            with problem_policy(4, 32):
+                step_shard_own()
+
+        arms = {"headline_step": step, "sweep_shard_path": step_shard, "sweep_whole_path": step_whole}
+        times = {k: [] for k in arms}
+        for _ in range(4):
+            for name, fn in arms.items():
+                w_, _ = timed_region(fn, 40, 3, dist, sync, device)
+                times[name].append(w_ / 40 * 1e3)
+        med = {k: _st.median(v) for k, v in times.items()}
+        fl = fwd_flops(b, s, s, h, d, causal)
+        state.clear()
+        torch.cuda.empty_cache()
+        extra["n1_consistency"] = {"what": "the headline step, the strong-scaling sweep's shard path at N = 1 and its whole-problem path: 4 interleaved rounds x 40 launches each, medians",
+                                   "median_ms": med, "tflops": {k: fl / v / 1e9 for k, v in med.items()}, "ms_per_round": times,
+                                   "shard_path_over_headline": med["headline_step"] / med["sweep_shard_path"],
+                                   "whole_path_over_headline": med["headline_step"] / med["sweep_whole_path"]}
     if not args.no_extra and dist.world > 1:
         del t
         torch.cuda.empty_cache()
-        state = {}
-
-        def make_point(seq, cz, plan):
-            # whole tensors on every rank (same seed), the rank's shard = strided views of them (no copy)
-            if state.get("seq") != seq:
-                state.clear()
-                torch.cuda.empty_cache()
-                w = make_inputs(torch, device, 4, seq, 32, 32, 128, "fp16", 99, False)
-                qs, os_ = shard_tensor(w["q"], plan, False), shard_tensor(w["o"], plan, False)
-                ks, vs = shard_tensor(w["k"], plan, True), shard_tensor(w["v"], plan, True)
-                lse_s = torch.empty(qs.shape[0], qs.shape[2], seq, device=device, dtype=torch.float32)
-                state.update(seq=seq, w=w, shard=(qs, ks, vs, os_, lse_s))
-            w, (qs, ks, vs, os_, lse_s) = state["w"], state["shard"]
-            ps = capi.fwd_params(qs, ks, vs, os_, lse_s, cz) if qs.numel() else None
-            pw = capi.fwd_params(w["q"], w["k"], w["v"], w["o"], w["lse"], cz)
-            return (lambda: capi.run_fwd(ps) if ps is not None else None), (lambda: capi.run_fwd(pw))
 
         extra["sweep_strong_b4_h32_d128_fp16"] = strong_scaling_sweep(dist, make_point, sync, device)
         state.clear()
@@ -934,7 +1001,32 @@ def main():
             if "mfma_16x16x32" in ceiling and "pp16" in fwd_kernel:
                 roofline["frac_of_sustained_measured_own_mfma_shape"] = k_tflops / ceiling["mfma_16x16x32"]["tflops"]
     if dist.rank == 0 and dist.world == 1:
-        roofline["ceiling"] = ceiling_block(args.workload, fwd_kernel, k_tflops, (ceiling or {}).get("rows"))
+        cb = ceiling_block(args.workload, fwd_kernel, k_tflops, (ceiling or {}).get("rows"))
+        roofline["ceiling"] = cb
+        # box-independent figures at the TOP level of `roofline` (scalars: the driver's parsed record keeps them), VERDICT r5 item 7
+        pm_after = power_capped_mfma_rate() if not args.no_extra else None
+        pms = [x for x in (pm_before, pm_after) if x]
+        if "pp16" in fwd_kernel and pms:
+            pm_mean = sum(pms) / len(pms)
+            roofline["power_capped_mfma_rate_tflops_before"] = pm_before
+            roofline["power_capped_mfma_rate_tflops_after"] = pm_after
+            roofline["frac_of_power_capped_mfma_rate"] = k_tflops / pm_mean
+            roofline["frac_of_power_capped_mfma_rate_at_median_launch"] = roofline["tflops_at_median_launch"] / pm_mean
+            roofline["power_capped_mfma_rate_what"] = ("chip-wide loop of v_mfma_f32_16x16x32_f16 on N(0,1) operands, one launch of >= 1 s at settled power before and one after "
+                                                       "the timed region (tools/clockbench --seconds 1); the frac uses their mean")
+        roofline["structure_probe_tflops"] = cb["chain_tflops"][2][1] if len(cb["chain_tflops"]) == 4 else None
+        roofline["shipped_over_structure_probe"] = cb.get("shipped_over_structure_probe")
+        roofline["mixed_stream_probe_tflops"] = cb.get("mixed_stream_probe_tflops")
+        roofline["shipped_over_mixed_stream_probe"] = cb.get("shipped_over_mixed_stream_probe")
+        if extra.get("d64_b4_s8192_h32_fp16") is not None and ceiling and ceiling.get("rows"):
+            # head_dim 64: twice the VALU work per FLOP - its own probes
+            rws = ceiling["rows"]
+            d64e = extra["d64_b4_s8192_h32_fp16"]
+            d64e["ceiling_probes_tflops"] = {"structure (two-group ping-pong, 190 VALU per phase)": rws.get(PROBE_PP_D64), "mixed stream (5.2 VALU + 1 KiB LDS per 32768 FLOP)": rws.get(PROBE_MIX_D64),
+                                             "pure v_mfma_f32_16x16x32": rws.get(PROBE_PURE16)}
+            for key in ("noncausal", "causal"):
+                if isinstance(d64e.get(key), dict) and rws.get(PROBE_PP_D64):
+                    d64e[key]["fwd_over_structure_probe"] = d64e[key]["fwd_tflops"] / rws[PROBE_PP_D64]
     if dist.rank == 0 and prof_digest and prof_digest != lib_digest:
         roofline["warning"] = (f"roofline.traffic comes from a profile of library build src={prof_digest}, this run timed src={lib_digest}: "
                                "re-run tools/round_evidence.sh on the current kernels")
@@ -944,6 +1036,7 @@ def main():
             "value": value, "unit": "TFLOP/s", "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, **contract_fields(args.workload, dist.world),
             "frac_of_fp16_mfma_peak": value / (PEAK_DENSE_FP16_TFLOPS * dist.world),
+            "tflops_at_median_launch": roofline["tflops_at_median_launch"] * dist.world,      # whole-job rate at the MEDIAN launch of a separate 30+ launch loop (less box noise than the K-step mean)
             "comm_backend": comm_backend, "library": capi.lib().fa_build_info().decode(), "git_commit": build_commit(),
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
             "device": {"name": prop.name or getattr(prop, "gcnArchName", ""), "arch": getattr(prop, "gcnArchName", ""), "cus": prop.multi_processor_count, "hbm_gib": prop.total_memory / 2**30,

@@ -137,29 +137,37 @@ def build_kernels(force=False):
             asm = s[:-4] + ".guard.s"
             cmd = [hipcc_path()] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-I", CSRC, "-I", INCLUDE, "-Wno-unused-command-line-argument", "--cuda-device-only", "-S", s, "-o", asm]
             scans.append((s, asm, subprocess.Popen(cmd)))
-    for p in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed")
-    for s, asm, p in scans:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed (M0 guard pass)")
-        with open(asm) as f:
-            n = m0_uses_outside_asm(f.read())
-        # MFMA-result guard (round 5): the accumulating MFMAs of the 16x16x32 kernels are inline asm, hipcc's hazard recogniser does not see them, and the forward's
-        # steady loop relies on the instructions between a tile's last MFMA and the first score read instead of a pad (fa_fwd_pp16.hip: `covered`).  mfma_hazards.py
-        # walks the ISA; a finding means this compiler scheduled a reader too close behind its MFMA.
-        sys.path.insert(0, HERE)
-        import mfma_hazards
+    sys.path.insert(0, HERE)
+    import mfma_hazards
 
-        found = {k: v for k, v in mfma_hazards.scan_file(asm).items() if v}
-        os.remove(asm)
-        if found:
-            k, v = next(iter(found.items()))
-            raise RuntimeError(f"{os.path.basename(s)}: {sum(len(x) for x in found.values())} instruction(s) touch an MFMA result before it has landed, e.g. in {k}: "
-                               f"line {v[0][0]} `{v[0][1]}` {v[0][4]} of {v[0][5]} wait states behind `{v[0][3]}` (flash-attention-turing_amd/mfma_hazards.py)")
-        if n:
-            raise RuntimeError(f"{os.path.basename(s)}: {n} use(s) of M0 outside the hand-written asm statements - the unsaved-M0 LDS-DMA of these kernels is "
-                               "no longer safe with this compiler / this edit (fa_params.hpp FA_BWD_DMA_SAVE_M0, fa_device.hpp dma16_to_lds_hidden)")
+    try:
+        for p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("hipcc failed")
+        for s, asm, p in scans:
+            if p.wait() != 0:
+                raise RuntimeError("hipcc failed (M0 guard pass)")
+            with open(asm) as f:
+                n = m0_uses_outside_asm(f.read())
+            # MFMA-result guard (round 5): the accumulating MFMAs of the 16x16x32 kernels are inline asm, hipcc's hazard recogniser does not see them, and the forward's
+            # steady loop relies on the instructions between a tile's last MFMA and the first score read instead of a pad (fa_fwd_pp16.hip: `covered`).  mfma_hazards.py
+            # walks the ISA; a finding means this compiler scheduled a reader too close behind its MFMA.
+            found = {k: v for k, v in mfma_hazards.scan_file(asm).items() if v}
+            if found:
+                k, v = next(iter(found.items()))
+                raise RuntimeError(f"{os.path.basename(s)}: {sum(len(x) for x in found.values())} instruction(s) touch an MFMA result before it has landed, e.g. in {k}: "
+                                   f"line {v[0][0]} `{v[0][1]}` {v[0][4]} of {v[0][5]} wait states behind `{v[0][3]}` (flash-attention-turing_amd/mfma_hazards.py)")
+            if n:
+                raise RuntimeError(f"{os.path.basename(s)}: {n} use(s) of M0 outside the hand-written asm statements - the unsaved-M0 LDS-DMA of these kernels is "
+                                   "no longer safe with this compiler / this edit (fa_params.hpp FA_BWD_DMA_SAVE_M0, fa_device.hpp dma16_to_lds_hidden)")
+    finally:
+        # (whatever failed, on whichever file - no stray processes, no .guard.s left in the source directory)
+        for p in procs + [x[2] for x in scans]:
+            if p.poll() is None:
+                p.wait()
+        for _, asm, _ in scans:
+            if os.path.exists(asm):
+                os.remove(asm)
     _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     _write_stamp(LIB_PATH, stamp)
     print(f"[build] {LIB_NAME} built in {time.time() - t0:.1f}s")
@@ -176,6 +184,11 @@ def build_debug_variants(force=False):
     if not todo:
         print("[build] debug variants up to date")
         return
+    # the variants link the PRODUCT's objects of every source they do not rebuild: an up-to-date library whose objects were cleaned (or never shipped) is rebuilt first
+    missing = [s for s in HIP_SOURCES if s not in DEBUG_SOURCES and not os.path.exists(os.path.join(CSRC, s[:-4] + ".o"))]
+    if missing:
+        print(f"[build] product objects missing ({', '.join(missing)}): rebuilding the library before the debug variants")
+        build_kernels(force=True)
     t0 = time.time()
     procs = []
     for n, flags in todo:
@@ -224,9 +237,12 @@ def build_torch_module(force=False):
     return EXT_PATH
 
 
-def build_all(force=False, torch_module=True):
+def build_all(force=False, torch_module=True, debug_variants=True):
+    """debug_variants: the four test builds of tests/test_dma_protocol_gpu.py (csrc/debug/, ~8 extra compiles; never packaged).  An in-tree developer / CI build wants
+    them (the GPU suite loads them), an installation does not: setup.py and `build.py --no-debug` leave them out."""
     build_kernels(force)
-    build_debug_variants(force)
+    if debug_variants:
+        build_debug_variants(force)
     if torch_module:
         build_torch_module(force)
 
@@ -235,6 +251,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--no-torch", action="store_true", help="only build the C-ABI kernel library")
+    ap.add_argument("--no-debug", action="store_true", help="skip the test builds of csrc/debug/ (tests/test_dma_protocol_gpu.py needs them)")
     a = ap.parse_args()
-    build_all(a.force, not a.no_torch)
+    build_all(a.force, not a.no_torch, not a.no_debug)
     sys.exit(0)

@@ -796,7 +796,7 @@ constexpr int64_t kKvMfma16MinPairs = (int64_t)1 << 20;       // seqlen_q * seql
 // epilogue and balance uneven tiles); dK/dV without a mask 0.97 / 1.01 / 0.97 / 0.95 / 0.94 / 0.95, under one 1.02 / 1.06 / 1.04 / 1.00-1.04 / 0.96-1.00.
 // FA_POLICY_AUTO follows those signs per head: seqlen_q * seqlen_k from which the 16x16x32 kernel serves (0 = never).
 #ifndef FA_BWD_D64_DQ16_MIN_PAIRS
-#define FA_BWD_D64_DQ16_MIN_PAIRS 1
+#define FA_BWD_D64_DQ16_MIN_PAIRS ((int64_t)1 << 18)      // 512 x 512: the shortest sequence of the A/B above (until round 6 every non-causal dQ down to 1 x 1 went to the one-workgroup-per-unit kernel unmeasured)
 #endif
 #ifndef FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL
 #define FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL ((int64_t)1 << 26)
@@ -825,7 +825,10 @@ static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
         const int64_t wgs = policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_q + 255) / 256), cus = device_cu_count();
         return kp.is_causal ? (wgs >= 2 * cus && (int64_t)kp.seqlen_q * kp.seqlen_k >= kKvMfma16MinPairs) : wgs >= cus;
     }
-    return (int64_t)kp.seqlen_q * kp.seqlen_k >= kKvMfma16MinPairs;
+    // dK/dV: from 1k x 1k whatever the launch (0.91-0.98 on every grid measured), and from 512 x 512 when the launch brings two 128-key workgroups per compute unit
+    // (b4 h32 s512: 0.966; b1 h8: 1.00-1.01, b1 h32 / b2 h16: 0.98: profiles/r6_policy_small_grids.log)
+    const int64_t pairs = (int64_t)kp.seqlen_q * kp.seqlen_k;
+    return pairs >= kKvMfma16MinPairs || (pairs >= ((int64_t)1 << 18) && policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_k + 127) / 128) >= 2 * device_cu_count());
 }
 const char* bwd_kernel_name_for(const BwdKernelParams& kp, bool dkdv) {
     return dkdv ? (bwd_use_mfma16(kp, true) ? "fa_bwd_dkdv16_kernel" : "fa_bwd_dkdv_kernel") : (bwd_use_mfma16(kp, false) ? "fa_bwd_dq16_kernel" : "fa_bwd_dq_kernel");

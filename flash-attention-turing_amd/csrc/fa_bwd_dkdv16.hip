@@ -31,12 +31,12 @@ namespace fa {
 #ifndef FA_KV16_DMA_EARLY
 #define FA_KV16_DMA_EARLY 0   // which q-half group requests the next tile at the top of the loop (the other one after its S / dP MFMAs); 2 = both at the top
 #endif
-// FA_KV16_DMA_STAGGER (round 6 experiment): four request points per tile instead of two - waves 0, 1 at the top of the tile, waves 2, 3 behind the second k-step of their
-// S / dP MFMAs, waves 4, 5 behind their S / dP MFMAs, waves 6, 7 behind their exponentials - so that at most two waves (on different SIMDs, never SIMD partners) queue at the
-// CU's address path at a time.  (Not the per-wave spread of round 5: a wave still issues its four pieces back to back.)
-#ifndef FA_KV16_DMA_STAGGER
-#define FA_KV16_DMA_STAGGER 0
-#endif
+// (Round 6, measured and not kept - the switches were never part of a committed product build; the logs say what was built:
+//   FA_KV16_DMA_STAGGER, three / four request points per tile instead of two: -2.3..+2.5 % (three) / +11..19 % (four), profiles/r6_dkdv_dma_stagger_ab.log;
+//   FA_KV16_SKEW, the two q-half groups a whole phase apart (one instruction stream, waves 4-7 with their barrier behind the score phase, waves 0-3 behind the dV / dK phase, three-slot
+//   rings): bit-identical, -0.4..+8.7 %, profiles/r6_dkdv_skew_ab.log - the pair is not in lock-step to begin with: at priority 1 waves 4-7 run ~800 cycles ahead inside a tile and
+//   wait at the barrier (profiles/r6_dkdv16_phase_timing.log), and hipcc moves the exponentials into the dV / dK phase's fragment prologue;
+//   FA_KV16_Q1_DUTIES, all requests (and the statistics) by waves 4-7, which have that slack: +0.2..+12 %, profiles/r6_dkdv_q1_duties_ab.log.)
 // (Round 5, measured and not kept - code in the history at 1ef1631: FA_KV16_DMA_SPREAD, the four pieces issued one by one between the MFMAs of the S / dP k-steps
 // (+1.5..6 %) or of the dV / dK fragment steps (+5..23 %) instead of back to back, profiles/r5_bwd_dkdv_dma_spread_ab.log.)
 #ifndef FA_KV16_STAT_PRED
@@ -295,11 +295,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
         FA_LDS char* sbuf = stat + buf * STATB;
 #endif
         const bool more = (it + 1 < n_iters);
-#if FA_KV16_DMA_STAGGER
-        // request point of this wave: 0 top, 1 mid S / dP, 2 behind S / dP, 3 behind the exponentials  (2 = three points: waves 0, 1 top; 2, 3 behind the exponentials; 4-7 behind S / dP)
-        const int dma_pt = FA_KV16_DMA_STAGGER == 2 ? (wave < 2 ? 0 : wave < 4 ? 3 : 2) : wave >> 1;
-        if (more && dma_pt == 0) issue_tile(buf ^ 1);
-#elif !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
+#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
         if (more && (FA_KV16_DMA_EARLY == 2 || qh == FA_KV16_DMA_EARLY)) issue_tile(buf ^ 1);          // ring slot buf^1 was last read in iteration it-1; waves 4-7 issue after their S / dP MFMAs
 #endif
         // Only the two statistics waves need this load, and a vector-memory instruction costs its wave ~100 cycles whatever it returns.  A LANE-dependent condition
@@ -358,20 +354,15 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
                         sacc[i][kc] = LP<T>::mfma16(qa[i], kreg[ks][kc], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sacc[i][kc]);      // S = Q K^T
                         dpacc[i][kc] = LP<T>::mfma16(da[i], vf[kc], ks == 0 ? nd4[i] : dpacc[i][kc]);                              // dP - D = dO V^T - D
                     }
-#if FA_KV16_DMA_STAGGER == 1
-                if (ks == KS / 2 - 1 && more && dma_pt == 1) issue_tile(buf ^ 1);
-#endif
             }
             FA_KV16_STAMP(1);                               // S / dP MFMAs (with their row-fragment reads)
 #if FA_KV16_DMA_DEBUG == 2
             if (more && qh == 1) asm volatile("s_sleep 64" ::: "memory");
 #endif
-#if FA_KV16_DMA_STAGGER
-            if (more && dma_pt == 2) issue_tile(buf ^ 1);
-#elif !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
+#if !(FA_KV16_ABL & 16) && FA_KV16_DMA_DEBUG != 1
             if (more && FA_KV16_DMA_EARLY != 2 && qh == (FA_KV16_DMA_EARLY ^ 1)) issue_tile(buf ^ 1);      // waves 4-7 request their pieces HERE, while waves 0-3 are still in their S / dP MFMAs
 #endif
-#if FA_KV16_DMA_DEBUG != 1 && !FA_KV16_DMA_STAGGER
+#if FA_KV16_DMA_DEBUG != 1
             if (more) pf_advance();
 #endif
             FA_KV16_STAMP(2);                               // LDS-DMA requests (waves 4-7), descriptors of the next tile
@@ -400,10 +391,6 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sacc[i][kc][r] = (16 * i + r >= thr[kc]) ? sacc[i][kc][r] : 0.f;
             }
-#if FA_KV16_DMA_STAGGER
-            if (more && dma_pt == 3) issue_tile(buf ^ 1);
-            if (more) pf_advance();
-#endif
             // P and dS = P * (dP - D) (:1354), rounded (:1359-1360), as the B operands of the half's 32-query contraction
             u32x4 pfr[2], dsfr[2];
 #pragma unroll

@@ -29,6 +29,8 @@ constexpr int kDq16BlockM = 256;
 #ifndef FA_DQ16_STAGGER_DMA
 #define FA_DQ16_STAGGER_DMA 1
 #endif
+// (Round 6, measured and not kept: FA_DQ16_SKEW - waves 4-7 with their workgroup barrier in FRONT of the tile's last dQ phase, so that the two waves of a SIMD stay a phase
+// apart; three-slot K / V rings, loop unrolled x3, no spill in the loops: bit-identical, +1.7..+10 %, profiles/r6_dq_skew_ab.log.)
 
 // FA_DQ16_MIN_WAVES: waves per SIMD the register budget is cut for.  head_dim 64 (round 5): 2 = one workgroup per compute unit on up to 256 registers,
 // 4 = two co-resident workgroups on 128 (what the 32x32x16 head_dim-64 kernel runs with).

@@ -211,14 +211,14 @@ const char* fa_fwd_kernel_name(int32_t d);
  * the 32x32x16 forward needs fewer cycles and wins short ones and launches that leave compute units idle.  FA_POLICY_AUTO (the default, head_dim 128, round 6): the
  * forward and dQ go to the 16x16x32 set when the launch has at least one 256-row workgroup per compute unit (batch x heads x ceil(seqlen_q / 256) >= CUs; under a causal
  * mask two per unit, or one with seqlen_q * seqlen_k >= 2^26) and, forward and causal dQ, seqlen_q * seqlen_k >= 2^20; dK/dV from seqlen_q * seqlen_k >= 2^20 whatever the
- * launch.  Because the choice follows the LAUNCH, a (batch, head) shard of a problem may get the other kernel set than the whole problem would: a caller that wants the
+ * launch (from 2^18 when it brings two 128-key workgroups per compute unit).  Because the choice follows the LAUNCH, a (batch, head) shard of a problem may get the other kernel set than the whole problem would: a caller that wants the
  * whole problem's kernels, hence its bits, on every shard states the whole problem's batch x heads with fa_set_policy_problem_heads() before it runs the shards (rounds
  * 3-5 chose per head only; flash_attn_turing/sharding.py:problem_policy does it for the Python surface).  One more exception stays: dK / dV of a GQA / MQA call that is given a
  * workspace - how far a head group is split, hence the order its partial sums are added in, follows the launch's workgroup count and the
  * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit.  FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
  * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has both forward kernels since round 4 - FA_POLICY_AUTO sends fp16
  * problems from 2^24 pairs per head (2^26 causal) to the 16x16x32 one, whose softmax row sums ride the matrix pipe (-2..5 %), and keeps bf16 on the
- * 32x32x16 one - and both backward sets since round 5: FA_POLICY_AUTO gives dQ to the 16x16x32 kernel without a mask at every length and under a
+ * 32x32x16 one - and both backward sets since round 5: FA_POLICY_AUTO gives dQ to the 16x16x32 kernel without a mask from 2^18 pairs per head (until round 6: at every length) and under a
  * causal mask from 2^26 pairs per head, dK/dV from 2^24 (2^28 causal), never when a causal problem has fewer keys than queries (-8..-11 % / -4..-6 %
  * where it serves; both dtypes).  The pinned policies apply to every head_dim, stage and dtype.  The reference has no counterpart.
  * Precision contract of the forward's softmax row sums: fp16 inputs on the 16x16x32 kernel sum the ROUNDED P in the matrix pipe after an exactly

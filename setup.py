@@ -33,7 +33,7 @@ def _fa_build():
 class BuildPyWithKernels(build_py):
     def run(self):
         fa = _fa_build()
-        fa.build_all(force=False, torch_module=True)
+        fa.build_all(force=False, torch_module=True, debug_variants=False)      # (the test builds of csrc/debug are not part of an installation)
         super().run()
         dst = os.path.join(self.build_lib, "flash_attn_turing")
         os.makedirs(os.path.join(dst, "include"), exist_ok=True)

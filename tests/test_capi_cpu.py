@@ -59,7 +59,8 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.kernel_name("fwd", 64, 512, 512, 32, 128, False) == "fa_fwd_pp_kernel"            # 2^18 pairs per head
     assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 128, False) == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 128, False) == "fa_bwd_dkdv16_kernel"
-    assert capi.kernel_name("dkdv", 4, 512, 512, 32, 128, True) == "fa_bwd_dkdv_kernel"
+    assert capi.kernel_name("dkdv", 4, 512, 512, 32, 128, True) == "fa_bwd_dkdv16_kernel"        # round 6: 512 x 512 when the launch has two workgroups per CU (here 512)
+    assert capi.kernel_name("dkdv", 1, 512, 512, 32, 128, True) == capi.kernel_name("dkdv", 64, 256, 256, 32, 128, False) == "fa_bwd_dkdv_kernel"
     # per launch (round 6) - unless the caller states the whole problem's batch x heads: a (batch, head) shard then gets the kernel of the whole problem
     assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == "fa_fwd_pp_kernel" and capi.kernel_name("fwd", 64, 16384, 16384, 64, 128, True) == "fa_fwd_pp16_kernel"
     assert capi.set_policy_problem_heads(64 * 64) == 0
@@ -67,12 +68,13 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.set_policy_problem_heads(0) == 64 * 64 and capi.lib().fa_set_policy_problem_heads(-5) == -1 and capi.set_policy_problem_heads(0) == 0
     assert capi.kernel_name("fwd", 1, 16384, 16384, 1, 128, True) == "fa_fwd_pp_kernel"
     assert capi.kernel_name("dkdv", 1, 8192, 8192, 2, 128, True) == "fa_bwd_dkdv16_kernel"       # dK/dV: by the pairs per head whatever the launch
-    # head_dim 64 backward (round 5): dQ 16x16x32 without a mask at every length and under one from 2^26 pairs per head; dK/dV from 2^24 (2^28 causal);
+    # head_dim 64 backward (round 5): dQ 16x16x32 without a mask from 2^18 pairs per head (round 6) and under one from 2^26; dK/dV from 2^24 (2^28 causal);
     # never when a causal problem has fewer keys than queries (dead row blocks); both dtypes
     assert capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, False) == capi.kernel_name("dkdv", 1, 4096, 4096, 1, 64, False, "bf16") == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dkdv", 4, 2048, 2048, 32, 64, False) == capi.kernel_name("dkdv", 4, 8192, 8192, 32, 64, True) == "fa_bwd_dkdv_kernel"
     assert capi.kernel_name("dkdv", 4, 16384, 16384, 32, 64, True) == "fa_bwd_dkdv16_kernel"
     assert capi.kernel_name("dq", 4, 512, 512, 32, 64, False) == capi.kernel_name("dq", 4, 8192, 8192, 32, 64, True) == "fa_bwd_dq16_kernel"
+    assert capi.kernel_name("dq", 4, 256, 256, 32, 64, False) == capi.kernel_name("dq", 1, 1, 1, 1, 64, False) == "fa_bwd_dq_kernel"      # round 6: non-causal dQ from 2^18 pairs per head (was: always)
     assert capi.kernel_name("dq", 4, 4096, 4096, 32, 64, True) == capi.kernel_name("dq", 4, 16384, 8192, 32, 64, True) == "fa_bwd_dq_kernel"
     assert capi.lib().fa_kernel_name(9, 1, 1, 1, 1, 128, 0) == b""
 

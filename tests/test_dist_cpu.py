@@ -174,19 +174,22 @@ def test_clockbench_parser_reads_the_current_table_and_reports_drift():
 
 
 def test_ceiling_block_decomposes_the_gap_to_peak():
-    """`roofline.ceiling`: nominal peak -> power-capped pure-MFMA rate of the kernel's own MFMA shape (live clockbench rows) ->
-    same structure with LDS reads / exponentials / DMA compiled out (committed ablation ratios) -> shipped; pure host arithmetic, checked here"""
+    """`roofline.ceiling`: nominal peak -> power-capped pure-MFMA rate of the kernel's own MFMA shape -> the kernel's own structure without its
+    dependencies (the 16x16x32 two-group ping-pong probe) -> shipped, all from live clockbench rows of the kernel's own MFMA shape; the mixed-stream probe and the
+    committed ablation ratios stand beside the chain.  Pure host arithmetic, checked here on the committed round-6 table"""
     sys.path.insert(0, ROOT)
     import bench
 
-    rows = bench.parse_clockbench_rows("variant   min   median      max  (TFLOP/s over 5 interleaved runs)\n"
-                                       "MFMA only, 2 waves/SIMD                                  1600     1656     1658\n"
-                                       "16x16x32 MFMA only, 2 waves/SIMD                         1911     2000     2004\n"
-                                       "MFMA + 4 VALU + 1 KB LDS (b128+tr mix), 2 w/SIMD         1248     1257     1263\n")
-    assert rows["16x16x32 MFMA only, 2 waves/SIMD"] == 2000 and rows["MFMA only, 2 waves/SIMD"] == 1656
+    with open(os.path.join(ROOT, "profiles", "r6_clockbench_instruction_mix.log")) as f:
+        rows = bench.parse_clockbench_rows(f.read().split("grid 1)")[0])                 # (the chip-wide table; the one-CU table follows it in the file)
+    assert rows[bench.PROBE_PURE16] > rows["MFMA only, 2 waves/SIMD"] > 1000
+    for k in (bench.PROBE_MIX_D128, bench.PROBE_PP_D128, bench.PROBE_MIX_D64, bench.PROBE_PP_D64):
+        assert 800 < rows[k] < rows[bench.PROBE_PURE16], k                                 # the labels bench.py looks up exist in tools/clockbench's table
     c = bench.ceiling_block("c3", "fa_fwd_pp16_kernel", 1260.0, rows)
-    assert c["pure_mfma_on_n01_operands_tflops"]["this_kernels_mfma_shape"] == 2000 and c["frac_of_power_capped_mfma_rate"] == 1260.0 / 2000
-    assert c["chain_tflops"][0][1] == 2500.0 and c["chain_tflops"][-1][1] == 1260.0
+    assert c["pure_mfma_on_n01_operands_tflops"]["this_kernels_mfma_shape"] == rows[bench.PROBE_PURE16] and c["frac_of_power_capped_mfma_rate"] == 1260.0 / rows[bench.PROBE_PURE16]
+    assert c["chain_tflops"][0][1] == 2500.0 and c["chain_tflops"][-1][1] == 1260.0 and len(c["chain_tflops"]) == 4
+    assert c["chain_tflops"][2][1] == rows[bench.PROBE_PP_D128] and c["shipped_over_structure_probe"] == 1260.0 / rows[bench.PROBE_PP_D128]
+    assert c["shipped_over_mixed_stream_probe"] == 1260.0 / rows[bench.PROBE_MIX_D128]
     vals = [v for _, v in c["chain_tflops"]]
     assert vals == sorted(vals, reverse=True), vals                                   # every step of the chain costs something
     prod = 1.0
@@ -195,7 +198,8 @@ def test_ceiling_block_decomposes_the_gap_to_peak():
     assert abs(prod - 1260.0 / 2500.0) < 1e-12
     if "same_structure_ablated" in c:                                                   # (a committed profiles/rNN_fwd_ceiling_ablations.json exists)
         assert 0.5 < c["same_structure_ablated"]["time_ratio_vs_shipped"]["no_lds_reads_no_exp_no_dma"] < 1.0
-    assert bench.ceiling_block("c3", "fa_fwd_pp_kernel", 1200.0, rows)["pure_mfma_on_n01_operands_tflops"]["this_kernels_mfma_shape"] == 1656
+    c32 = bench.ceiling_block("c3", "fa_fwd_pp_kernel", 1200.0, rows)                   # the 32x32x16 kernel: its own pure-MFMA row, no 16x16x32 structure probe
+    assert c32["pure_mfma_on_n01_operands_tflops"]["this_kernels_mfma_shape"] == rows["MFMA only, 2 waves/SIMD"] and len(c32["chain_tflops"]) == 3
     assert bench.ceiling_block("c3", "fa_fwd_pp16_kernel", 1260.0, None)["chain_tflops"][0][1] == 2500.0      # clockbench missing: still a block
 
 

@@ -192,6 +192,21 @@ def test_hazard_scan_sees_the_round5_pathology_and_hipccs_own_spacing():
 	s_nop 10
 	v_accvgpr_read_b32 v1, a3""".split("\n")
     assert len(scan_kernel(early, 0, len(early))) == 1
+    # (round 6, ADVICE r5) a reader at a LOOP TOP behind an MFMA at the loop's tail: seen through the back edge, and only through it
+    loop = """k:
+.LBB0_1:
+	v_add_f32 v9, v0, v0
+	s_nop 7
+	s_nop 7
+	v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[4:7], v[0:3]
+	s_cbranch_vccnz .LBB0_1
+	s_nop 7
+	v_add_f32 v9, v0, v0""".split("\n")
+    v = scan_kernel(loop, 0, len(loop))
+    assert len(v) == 1 and v[0][0] == 3 and v[0][4] == 1          # line 3 (the loop's first instruction), one wait state behind the MFMA (the branch)
+    spaced = [l for l in loop]
+    spaced.insert(2, "\ts_nop 7")                                  # eight states at the loop top: clean
+    assert scan_kernel(spaced, 0, len(spaced)) == []
 
 
 def test_guard_detects_the_known_pathology():

@@ -86,3 +86,23 @@ def test_varlen_with_equal_lengths_costs_what_the_dense_batch_costs(causal):
     dense_b = _median_ms(lambda: capi.mha_bwd(q, k, v, o, lse, do, dq, dk, dv, dsum, causal))
     var_f, var_b = _median_ms(vfwd), _median_ms(vbwd)
     assert var_f / dense_f < 1.20 and var_b / dense_b < 1.20, (var_f / dense_f, var_b / dense_b)
+
+
+def test_n1_row_of_the_strong_scaling_sweep_agrees_with_the_headline(gpu):
+    """at N = 1 the headline path (`value`: 20 launches of the whole problem) and the strong-scaling sweep's row for the same shape (plan_shards ->
+    shard views -> prepared params -> launches under the whole problem's kernel policy, timed by the same bracket, interleaved with the headline step: medians of 4 rounds) must tell the same rate, so that the first real
+    1 / 2 / 4 / 8-GPU run can only debut RCCL itself.  The driver's own command line plus --no-extra --n1-consistency (the other extras do not matter here)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extra", "--no-cpu-baseline", "--n1-consistency"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["extra"]["n1_consistency"]
+    print(c)
+    assert abs(c["shard_path_over_headline"] - 1.0) <= 0.01, c          # (rates: > 1 = the sweep's shard path is the faster one)
+    assert abs(c["whole_path_over_headline"] - 1.0) <= 0.01, c
