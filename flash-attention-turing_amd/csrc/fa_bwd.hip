@@ -812,10 +812,20 @@ static bool bwd_use_mfma16(const BwdKernelParams& kp, bool dkdv) {
     if ((kp.d != 128 && kp.d != 64) || policy == 0) return false;
     if (policy == 1) return true;
     if (kp.d == 64) {
-        const int64_t min_pairs = dkdv ? (kp.is_causal ? (int64_t)FA_BWD_D64_DKDV16_MIN_PAIRS_CAUSAL : (int64_t)FA_BWD_D64_DKDV16_MIN_PAIRS)
-                                       : (kp.is_causal ? (int64_t)FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL : (int64_t)FA_BWD_D64_DQ16_MIN_PAIRS);
         // (seqlen_k < seqlen_q under a mask: blocks of dead rows, where the narrow kernels are ahead)
-        return min_pairs > 0 && (int64_t)kp.seqlen_q * kp.seqlen_k >= min_pairs && !(kp.is_causal && kp.seqlen_k < kp.seqlen_q);
+        if (kp.is_causal && kp.seqlen_k < kp.seqlen_q) return false;
+        // Round 6: the per-head thresholds of round 5 hold for launches that fill the chip; a launch that leaves the second workgroup slot of the 32x32x16 kernels empty is
+        // 5-25 % faster on the one-workgroup 16x16x32 kernels at every length (ratio 16 / 32, fp16, b1 h8 / b1 h32: dQ 0.75-0.90, dK/dV 0.81-0.96), and a launch of many short
+        // sequences (b16 h32 s512-1k) is 3-24 % faster on the 32x32x16 dQ: profiles/r6_policy_d64_before.log / r6_policy_d64.log.
+        const int64_t pairs = (int64_t)kp.seqlen_q * kp.seqlen_k, cus = device_cu_count();
+        if (dkdv) {
+            const int64_t wgs = policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_k + 127) / 128);      // (query heads: the unit of work, and what a shard states)
+            if (kp.is_causal) return pairs >= (int64_t)FA_BWD_D64_DKDV16_MIN_PAIRS_CAUSAL || wgs <= 2 * cus || (wgs <= 4 * cus && pairs >= ((int64_t)1 << 24));
+            return pairs >= (int64_t)FA_BWD_D64_DKDV16_MIN_PAIRS || wgs <= 2 * cus;
+        }
+        const int64_t wgs = policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_q + 255) / 256);
+        if (kp.is_causal) return pairs >= (int64_t)FA_BWD_D64_DQ16_MIN_PAIRS_CAUSAL || wgs <= 2 * cus;
+        return pairs >= (int64_t)FA_BWD_D64_DQ16_MIN_PAIRS && !(wgs >= 4 * cus && pairs < ((int64_t)1 << 22));
     }
     // dQ (round 6): like the forward, by whether the launch fills the chip - from one 256-row workgroup per compute unit without a mask, from two under one (and then
     // from 1k x 1k).  Ratio 16 / 32 (profiles/r6_policy_small_grids.log, r5_policy_sweep_after_trim.log): no mask b1 h8 1.05 at 512-4k (16-128 workgroups), 0.92 at 8k

@@ -601,7 +601,16 @@ static bool use_mfma16(const FwdKernelParams& kp, int dtype) {
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
     if (policy == 0 || (kp.d != 128 && kp.d != 64)) return false;
     if (policy == 1) return true;
-    if (kp.d == 64) return dtype == 0 && (int64_t)kp.seqlen_q * kp.seqlen_k >= (kp.is_causal ? kFwdD64Mfma16MinPairsCausal : kFwdD64Mfma16MinPairs);
+    if (kp.d == 64) {
+        // Round 6: at head_dim 64 the launch matters the other way round.  The 32x32x16 kernel lives off two co-resident workgroups per compute unit; a launch that cannot fill
+        // both slots leaves it behind the one-workgroup 16x16x32 kernel by 8-21 % from 2k x 2k (ratio 16 / 32, fp16: no mask b1 h32 2k 0.92, b1 h8 2k 0.975 / 4k 0.92; causal
+        // b1 h32 1k 0.965 / 2k 0.91 / 4k 0.79, b1 h8 1k 0.96 .. 4k 0.86), while full launches keep the round-4 thresholds (b4 h32: 1.02-1.11 at 2k-4k causal, b16 h32: 1.07-1.33
+        // below 4k): profiles/r6_policy_d64_before.log / r6_policy_d64.log.  bf16 keeps its VALU row sums and stays on the 32x32x16 kernel.
+        if (dtype != 0) return false;
+        const int64_t pairs = (int64_t)kp.seqlen_q * kp.seqlen_k, wgs = policy_bh(kp.b, kp.h) * (((int64_t)kp.seqlen_q + 255) / 256), cus = device_cu_count();
+        if (kp.is_causal) return pairs >= kFwdD64Mfma16MinPairsCausal || (pairs >= ((int64_t)1 << 22) && wgs <= 2 * cus) || (pairs >= ((int64_t)1 << 20) && 2 * wgs <= cus);
+        return pairs >= kFwdD64Mfma16MinPairs || (pairs >= ((int64_t)1 << 22) && wgs <= cus);
+    }
     // (packed sequences: max_seqlen_q x max_seqlen_k and the plain grid's workgroup count; never total_q - the optional hint must not change which kernel,
     // hence which bits, a call gets: tests/test_fuzz_gpu.py compares the compact and the plain varlen grid bit for bit)
     const int64_t pairs = (int64_t)kp.seqlen_q * kp.seqlen_k;

@@ -216,10 +216,12 @@ const char* fa_fwd_kernel_name(int32_t d);
  * 3-5 chose per head only; flash_attn_turing/sharding.py:problem_policy does it for the Python surface).  One more exception stays: dK / dV of a GQA / MQA call that is given a
  * workspace - how far a head group is split, hence the order its partial sums are added in, follows the launch's workgroup count and the
  * device's CU count; shards then agree with the whole problem to a last rounding, not bit for bit.  FA_POLICY_MFMA32 / FA_POLICY_MFMA16 pin one set for every launch.  Process-wide, thread-safe; returns the
- * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has both forward kernels since round 4 - FA_POLICY_AUTO sends fp16
- * problems from 2^24 pairs per head (2^26 causal) to the 16x16x32 one, whose softmax row sums ride the matrix pipe (-2..5 %), and keeps bf16 on the
- * 32x32x16 one - and both backward sets since round 5: FA_POLICY_AUTO gives dQ to the 16x16x32 kernel without a mask from 2^18 pairs per head (until round 6: at every length) and under a
- * causal mask from 2^26 pairs per head, dK/dV from 2^24 (2^28 causal), never when a causal problem has fewer keys than queries (-8..-11 % / -4..-6 %
+ * previous policy, -1 (and changes nothing) for an unknown value.  head_dim 64 has both forward kernels since round 4 and both backward sets since round 5; there the
+ * launch matters the other way round: the 32x32x16 kernels live off two co-resident workgroups per compute unit, so FA_POLICY_AUTO keeps them for launches that fill the
+ * chip with short sequences and gives the 16x16x32 set (one workgroup per unit) the long sequences - fp16 forward from 2^24 pairs per head (2^26 causal), dQ without a mask
+ * from 2^18 and under one from 2^26, dK/dV from 2^24 (2^28 causal) - AND, since round 6, every launch that leaves the second workgroup slot empty (forward: at most one
+ * 256-row workgroup per unit from 2^22 pairs, two under a mask, half a one from 2^20; dQ / dK/dV under a mask: at most two per unit; 5-25 % there), never when a causal
+ * problem has fewer keys than queries; bf16 forwards stay on the 32x32x16 kernel (-8..-11 % / -4..-6 %
  * where it serves; both dtypes).  The pinned policies apply to every head_dim, stage and dtype.  The reference has no counterpart.
  * Precision contract of the forward's softmax row sums: fp16 inputs on the 16x16x32 kernel sum the ROUNDED P in the matrix pipe after an exactly
  * summed prefix of 1024 keys (LSE within 5e-5 of fp32 math at the BASELINE sizes); bf16 inputs keep exact fp32 VALU sums on every kernel (LSE within

@@ -29,13 +29,16 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.kernel_name("fwd", 4, 16384, 16384, 32, 128, True) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 128, False) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 1, 512, 512, 4, 128, False) == "fa_fwd_pp_kernel"
-    # head_dim 64 (round 4): fp16 from 2^24 pairs per head (2^26 under a causal mask) on the 16x16x32 forward, bf16 never unless pinned
+    # head_dim 64: fp16 from 2^24 pairs per head (2^26 under a causal mask) on the 16x16x32 forward when the launch fills the chip, from 2k x 2k (1k x 1k causal) when it
+    # leaves the second workgroup slot of the 32x32x16 kernel empty (round 6); bf16 never unless pinned
     assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 64, False) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 4, 2048, 2048, 32, 64, False) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 1, 2048, 2048, 32, 64, False) == "fa_fwd_pp16_kernel"          # 256 workgroups
     assert capi.kernel_name("fwd", 4, 4096, 4096, 32, 64, True) == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 1, 4096, 4096, 32, 64, True) == capi.kernel_name("fwd", 1, 1024, 1024, 32, 64, True) == "fa_fwd_pp16_kernel"
     assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, True) == "fa_fwd_pp16_kernel"
-    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False, "bf16") == capi.kernel_name("fwd", 4, 16384, 16384, 32, 64, True, "bf16") == "fa_fwd_pp_kernel"
+    assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 64, False, "bf16") == capi.kernel_name("fwd", 4, 16384, 16384, 32, 64, True, "bf16") == capi.kernel_name("fwd", 1, 2048, 2048, 32, 64, False, "bf16") == "fa_fwd_pp_kernel"
     assert capi.kernel_name("fwd", 4, 8192, 8192, 32, 128, False, "bf16") == "fa_fwd_pp16_kernel"
     assert capi.lib().fa_kernel_name(0, 4, 8192, 8192, 32, 64, 0) == capi.lib().fa_kernel_name_dtype(0, 0, 4, 8192, 8192, 32, 64, 0)      # fa_kernel_name = fp16
     assert capi.lib().fa_kernel_name_dtype(0, 7, 4, 8192, 8192, 32, 64, 0) == b""
@@ -76,6 +79,11 @@ def test_forward_kernel_policy_is_host_state():
     assert capi.kernel_name("dq", 4, 512, 512, 32, 64, False) == capi.kernel_name("dq", 4, 8192, 8192, 32, 64, True) == "fa_bwd_dq16_kernel"
     assert capi.kernel_name("dq", 4, 256, 256, 32, 64, False) == capi.kernel_name("dq", 1, 1, 1, 1, 64, False) == "fa_bwd_dq_kernel"      # round 6: non-causal dQ from 2^18 pairs per head (was: always)
     assert capi.kernel_name("dq", 4, 4096, 4096, 32, 64, True) == capi.kernel_name("dq", 4, 16384, 8192, 32, 64, True) == "fa_bwd_dq_kernel"
+    # round 6: launches that leave the 32x32x16 kernels' second workgroup slot empty go to the 16x16x32 set at every length; many short sequences keep the 32x32x16 dQ
+    assert capi.kernel_name("dq", 1, 4096, 4096, 32, 64, True) == capi.kernel_name("dq", 1, 512, 512, 8, 64, True) == "fa_bwd_dq16_kernel"
+    assert capi.kernel_name("dkdv", 1, 1024, 1024, 32, 64, False) == capi.kernel_name("dkdv", 1, 4096, 4096, 32, 64, True) == capi.kernel_name("dkdv", 1, 2048, 2048, 8, 64, True) == "fa_bwd_dkdv16_kernel"
+    assert capi.kernel_name("dkdv", 1, 8192, 8192, 32, 64, True) == capi.kernel_name("dkdv", 4, 1024, 1024, 32, 64, True) == "fa_bwd_dkdv_kernel"
+    assert capi.kernel_name("dq", 16, 512, 512, 32, 64, False) == "fa_bwd_dq_kernel" and capi.kernel_name("dq", 16, 2048, 2048, 32, 64, False) == "fa_bwd_dq16_kernel"
     assert capi.lib().fa_kernel_name(9, 1, 1, 1, 1, 128, 0) == b""
 
 

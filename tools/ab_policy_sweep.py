@@ -22,7 +22,7 @@ for causal in (False, True):
         capi.mha_fwd(q, k, v, o, lse, causal); capi.bwd_stage("dq", pb); torch.cuda.synchronize()
         auto = {st: capi.kernel_name(st, a.b, s, s, a.h, a.d, causal, a.dtype) for st in ("fwd", "dq", "dkdv")}
         row = []
-        for st in (("fwd", "dq", "dkdv") if a.d == 128 else ("fwd",)):          # head_dim 64 has one backward set
+        for st in ("fwd", "dq", "dkdv"):
             f = (lambda: capi.mha_fwd(q, k, v, o, lse, causal)) if st == "fwd" else (lambda: capi.bwd_stage(st, pb))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); f(); f(); f(); e1.record(); e1.synchronize()
