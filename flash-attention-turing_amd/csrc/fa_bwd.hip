@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kDqThreads, FA_DQ_MIN_WAVES(D)) void fa_bwd_dq_kern
 // and the 32-row half qh = w >> 2 of every Q/dO tile; the two q-halves' partial dK^T / dV^T are
 // summed through LDS once, in the epilogue.
 //
-// Register plan (lessons of the first two versions): the 128 long-lived
+// Register plan (lessons of the first two versions, see profiles/NOTEBOOK.md 3): the 128 long-lived
 // accumulator registers live in AGPRs and are only touched by MFMAs (LP<T>::mfma_agpr, inline
 // asm "+a"); with -amdgpu-mfma-vgpr-form every other MFMA result stays in VGPRs where the softmax
 // VALU uses it directly, so there is no v_accvgpr shuttling; everything else fits 128 VGPRs, so

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kKvThreads, FA_KV16_MIN_WAVES(D)) void fa_bwd_dkdv1
         for (int kc = 0; kc < 2; ++kc) vreg[ks][kc] = lds_read16(vtile, row_rd[ks] + (kb * 32 + 16 * kc) * ROWB);
 
     // FA_KV_PRIO (round 4): issue priority between the two q-half groups, which share every SIMD pairwise.  Waves 0-3 are the older ones,
-    // win every arbitration and wait ~1000 of ~3700 cycles per tile at the barrier.  1 (shipped) = waves 4-7 at priority 1 for
+    // win every arbitration and wait ~1000 of ~3700 cycles per tile at the barrier (profiles/NOTEBOOK.md 3c).  1 (shipped) = waves 4-7 at priority 1 for
     // the whole loop: -1.1..-3.4 % on every shape but causal 2k (+0.3 %); 2 = the groups alternate tile by tile: +0..2 %; 3 = waves 0-3 at
     // priority 1 (control): -1..+1 %.  profiles/r4_bwd_dkdv_prio_ab.log.  (+1 inside the MFMA clusters, with or without the static offset: +1..6 %,
     // profiles/r4_prio_mfma_phase_ab.log.)

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;
     // k-slot permutations that keep the UNCHANGED LDS tile image (fa_device.hpp:lds_tile_off) bank-conflict free under the access patterns
-    // of 16x16x32 fragments (checked exhaustively against the service groups of ds_read_b128 / ds_read_b64_tr_b16):
+    // of 16x16x32 fragments (checked exhaustively against the service groups of ds_read_b128 / ds_read_b64_tr_b16, profiles/NOTEBOOK.md 3d):
     //   d chunks:  lane group g contracts over d = 32*ks + 8*kPi[g] + 0..7          (A = K rows from LDS, B = Q^T from HBM: same permutation)
     //   keys:      row i = 4*gi + r of score block kb is key 16*kb + 4*kPi2[gi] + r   (A = K row i; C rows 4*g + r; P.V k-slots; V^T tr reads)
     const int pi_g = (0x2130 >> (4 * g)) & 3;             // kPi  = {0, 3, 1, 2}

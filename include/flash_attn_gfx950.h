@@ -103,7 +103,7 @@ typedef struct fa_fwd_params {
     /* ABI 2, optional (0 = unknown).  varlen only: number of rows of the PACKED q / k tensors (what the reference's mha_varlen_fwd
      * sees as q.size(0) / k.size(0), flash_api.cpp:319-381).  MUST be >= cu_seqlens_q[b] / cu_seqlens_k[b] (like max_seqlen, the
      * library cannot check device values without synchronising).  When given, the launch grid is sized by the tokens actually
-     * present instead of max_seqlen x batch, which matters for batches of very unequal lengths (DESIGN.md, varlen). */
+     * present instead of max_seqlen x batch, which matters for batches of very unequal lengths (DESIGN.md 3, varlen). */
     int64_t total_q;
     int64_t total_k;
 } fa_fwd_params;

@@ -1,5 +1,5 @@
 // atomicbench.hip -- can dQ be accumulated across key blocks with fp32 atomics (the reference's own backward, flash_bwd_kernel.h: dq_accum +
-// atomicAdd) at the rate a single fused backward kernel would need on an MI355X?  
+// atomicAdd) at the rate a single fused backward kernel would need on an MI355X?  (profiles/NOTEBOOK.md 7, item 0.)
 //
 // The access pattern of that kernel at BASELINE configs[3] (b4 h32 s8192 d128), nothing else: one workgroup per (head, 128-key block) =
 // 128 heads x 64 blocks; each sweeps the 128 query tiles (64 rows x 128 d fp32 = 32 KiB) of its head's 4 MiB dq_accum and adds a tile's

@@ -1,6 +1,6 @@
 // powerbench.hip -- what the power-limited matrix pipes of an MI355X deliver as a function of the MFMA variant and of the DATA:
 // chip-wide dependency-free MFMA loops (2 waves / SIMD, 4 accumulators per wave), every variant 5x interleaved.  The attention
-// kernels run against a clock that falls as the pipes fill; this probe asks which knobs move that ceiling at all.
+// kernels run against a clock that falls as the pipes fill (profiles/NOTEBOOK.md 3c); this probe asks which knobs move that ceiling at all.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

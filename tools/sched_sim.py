@@ -2,7 +2,7 @@
 """List-scheduling model of a causal forward launch: workgroups reach the 8 XCDs round-robin (block id % 8) and the 32 compute units of an XCD
 take them in id order as they free up.  Compares the two orders of fa_device.hpp:decode_block - heaviest query tile first within each
 (batch, head) (round 3), tile index first across all heads, and the shipped order: groups of ceil(64 / tiles) heads, tile index first inside a group.  Cost of a workgroup = fixed + per-tile
-time x (4 t + 4) for its tile index t (256 query rows, 64-key tiles); the constants are the round-2 fit.  A model, not a
+time x (4 t + 4) for its tile index t (256 query rows, 64-key tiles); the constants are the round-2 fit (profiles/NOTEBOOK.md 4).  A model, not a
 measurement: profiles/r4_causal_tile_order_ab.log is the measurement."""
 import heapq
 
