@@ -99,7 +99,8 @@ constexpr float kPpDeferLog2 = 6.0f;
 // softmax pass apart instead of together behind the barrier: bit-identical, +9..41 % (the scalar branches inside the pass cost hipcc its schedule),
 // profiles/r6_fwd_dma_stagger_ab.log; FA_PP16_PK_FMA, the multiply-subtract in front of every exponential two scores at a time (v_pk_fma_f32, 95 -> 79 VALU per wave and
 // tile, bit-identical): +10..25 % - beside a partner wave that issues MFMAs a v_pk_fma_f32 takes 21 cycles where a v_fma_f32 takes 8 (tools/ubench, profiles/r6_ubench_cadence.log),
-// profiles/r6_fwd_pk_fma_ab.log.)
+// profiles/r6_fwd_pk_fma_ab.log; a SIMPLE instance - four waves, 128 rows, two-slot rings with the staging aliased (64 KiB), every tile through iteration(), TWO workgroups per
+// compute unit, for short sequences: value-correct on its first run and +3..+25 % slower from 512 to 4k (causal 512: -2..-5 %), profiles/r6_fwd_simple_two_per_cu_ab.log.)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
