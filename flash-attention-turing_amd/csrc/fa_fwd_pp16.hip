@@ -105,6 +105,14 @@ constexpr float kPpDeferLog2 = 6.0f;
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
 
+// FA_FWD_TIMING (round 6; timing builds only, the product does not define it and its ISA does not change): s_memtime stamps around the parts of a steady-loop step -
+// matrix phase, the barrier behind it, LDS-DMA requests, softmax pass, fragment prefetch + counted DMA wait, the barrier behind that - summed per wave over the unrolled loop and left,
+// with the step count, in the first 8 LSE entries of the wave's rows (LSE is WRONG in such a build; tools/phase_timing_fwd.py reads them, profiles/r6_fwd16_phase_timing.log)
+#ifdef FA_FWD_TIMING
+#define FA_FWD_STAMP(i) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[i] += (uint32_t)(now_ - tlast); tlast = now_; } while (0)
+#else
+#define FA_FWD_STAMP(i) do { } while (0)
+#endif
 // QB = 16-row query columns per wave: 2 (256-row workgroups, the product) or 3 (384 rows; every K / V^T fragment then feeds three MFMAs - a third
 // fewer LDS operand bytes per FLOP - with 32-key tiles so that S / P shrink enough for O (96) + Q (48) to stay at two waves per SIMD; round 5, FA_FWD_D128_QB)
 template <typename T, int D, bool CAUSAL, int BN, int QB = 2>
@@ -658,6 +666,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         advance_ring();
     };
 
+#ifdef FA_FWD_TIMING
+    uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u}, tsteps = 0u;
+    uint64_t tlast = 0;
+#endif
     int u = 0;
     if (n_main > 0) {
         iteration(0, no{});
@@ -666,7 +678,9 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         auto step_c = [&](int uu, auto um1, auto u0, auto up1, auto lsc, auto mlc) __attribute__((always_inline)) {
             constexpr int S_UM1 = decltype(um1)::value, S_U = decltype(u0)::value, S_UP1 = decltype(up1)::value;
             m_phase(S_UM1, S_U, lsc);
+            FA_FWD_STAMP(0);
             __syncthreads();
+            FA_FWD_STAMP(1);
 #if FA_PP16_ROLE_DMA
             // group A: K(u+2) -> the slot K(u-1) left (last read in M(u-1), which group B finished one barrier ago);
             // group B: V(u+2) -> the slot V(u-1) left (last read in M(u), which group B itself has just finished and group A one phase earlier).
@@ -687,12 +701,19 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
 #if !(FA_PP16_ABL & 2)
             dma_role_tile(uu + 2, S_UM1);
 #endif
+            FA_FWD_STAMP(2);
             softmax_step(uu, no{}, no{}, mlc, std::integral_constant<bool, FA_PP16_DMA_FUSED && !(FA_PP16_ABL & 2) && FA_PP16_SKIP_PAD && (BN * (D / 8) / 256 == 4 || BN * (D / 8) / 256 == 2)>{});      // (12 wait states with the two-piece statement)
+            FA_FWD_STAMP(3);
             m_prefetch(S_U, S_UP1);
 #if !(FA_PP16_ABL & 3)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW) : "memory");
 #endif
+            FA_FWD_STAMP(4);
             __syncthreads();
+            FA_FWD_STAMP(5);
+#ifdef FA_FWD_TIMING
+            ++tsteps;
+#endif
 #endif
 #elif FA_PP16_RACY
             // the WRONG form (see the header): V(u+1) first so that the K(u+2) pieces are the youngest; the counted wait retires V(u+1) and the K(u+1)
@@ -725,6 +746,10 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
         using i1 = std::integral_constant<int, 1>;
         using i2 = std::integral_constant<int, 2>;
         u = 1;
+#ifdef FA_FWD_TIMING
+        tlast = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #if FA_PP16_ROLE_DMA
         // entering the role-split loop: K(2) was requested by tile 0's iteration, V(2) by nobody yet (the symmetric scheme runs V one tile behind K)
         const bool role_loop = n_main >= 4;
@@ -787,6 +812,15 @@ __global__ __launch_bounds__(kFwdThreads, FA_PP_MIN_WAVES(D, BN)) void fa_fwd_pp
     for (; u < n_tiles; ++u) iteration(u, yes{});        // diagonal / ragged tiles
     if (prev_active) pv_step();
     epilogue(tile);
+#ifdef FA_FWD_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) lse_bh[tile * kFwdBlockM + wave * RW + i] = (float)tacc[i];
+        lse_bh[tile * kFwdBlockM + wave * RW + 6] = (float)tsteps;
+        lse_bh[tile * kFwdBlockM + wave * RW + 7] = (float)tile;
+    }
+#endif
     if (group == 0) __syncthreads();          // group A waits for B's last phase (equal barrier counts)
 }
 
