@@ -100,7 +100,11 @@ constexpr float kPpDeferLog2 = 6.0f;
 // profiles/r6_fwd_dma_stagger_ab.log; FA_PP16_PK_FMA, the multiply-subtract in front of every exponential two scores at a time (v_pk_fma_f32, 95 -> 79 VALU per wave and
 // tile, bit-identical): +10..25 % - beside a partner wave that issues MFMAs a v_pk_fma_f32 takes 21 cycles where a v_fma_f32 takes 8 (tools/ubench, profiles/r6_ubench_cadence.log),
 // profiles/r6_fwd_pk_fma_ab.log; a SIMPLE instance - four waves, 128 rows, two-slot rings with the staging aliased (64 KiB), every tile through iteration(), TWO workgroups per
-// compute unit, for short sequences: value-correct on its first run and +3..+25 % slower from 512 to 4k (causal 512: -2..-5 %), profiles/r6_fwd_simple_two_per_cu_ab.log.)
+// compute unit, for short sequences: value-correct on its first run and +3..+25 % slower from 512 to 4k (causal 512: -2..-5 %), profiles/r6_fwd_simple_two_per_cu_ab.log;
+// after the phase stamps (FA_FWD_TIMING below: the two sides of a step are balanced at ~1320 cycles): FA_PP16_ROWSUM_DOT2, the MFMA-summed tiles' row sums by v_dot2c_f32_f16 in the
+// softmax pass instead of four MFMAs per tile: +3..5 %, profiles/r6_fwd_rowsum_dot2_ab.log; FA_PP16_DMA_SPREAD, the four role pieces a quarter of the pass apart, branch-free: +9..56 %,
+// profiles/r6_fwd_dma_spread_ab.log; FA_PP16_DMA_IN_M, the pieces between the MFMAs of the wave's own matrix phase (K(u+2) / V(u+1) in M(u)): bit-identical, +5..10 % - a matrix phase that
+// issues VMEM stalls, profiles/r6_fwd_dma_in_m_ab.log.)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
