@@ -104,7 +104,9 @@ constexpr float kPpDeferLog2 = 6.0f;
 // after the phase stamps (FA_FWD_TIMING below: the two sides of a step are balanced at ~1320 cycles): FA_PP16_ROWSUM_DOT2, the MFMA-summed tiles' row sums by v_dot2c_f32_f16 in the
 // softmax pass instead of four MFMAs per tile: +3..5 %, profiles/r6_fwd_rowsum_dot2_ab.log; FA_PP16_DMA_SPREAD, the four role pieces a quarter of the pass apart, branch-free: +9..56 %,
 // profiles/r6_fwd_dma_spread_ab.log; FA_PP16_DMA_IN_M, the pieces between the MFMAs of the wave's own matrix phase (K(u+2) / V(u+1) in M(u)): bit-identical, +5..10 % - a matrix phase that
-// issues VMEM stalls, profiles/r6_fwd_dma_in_m_ab.log.)
+// issues VMEM stalls, profiles/r6_fwd_dma_in_m_ab.log; FA_PP16_ONE_BARRIER, one workgroup barrier per step (the instance between group A's matrix and softmax phase dropped, every slot hand-over
+// still fenced): bit-identical, +0.4..6.6 % - the groups drift out of their alternation and the older one starves its partner, profiles/r6_fwd_one_barrier_ab.log; FA_PP16_S_PRIO, issue
+// priority 1 / 2 during a wave's softmax side: +-1 %, head_dim 64 included, profiles/r6_fwd_softmax_prio_ab.log.)
 #ifndef FA_PP16_PF
 #define FA_PP16_PF 2        // LDS fragments in flight ahead of their MFMAs in a matrix phase (1-3 within 1 %, 2 best; 6: +1 %, 8: +2..4 %)
 #endif
